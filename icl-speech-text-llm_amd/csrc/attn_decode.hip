@@ -1,0 +1,123 @@
+// attn_decode.hip — single-token decode attention over the KV cache (HBM-bound KV stream).
+// Cache layout [n_seqs][n_heads][max_len][D] bf16: the keys of one (sequence, head) are one
+// contiguous stream, read with 16-B loads straight to VGPRs (no LDS round trip: guide §5 table row
+// "GEMV / M <= 16 decode").  D/8 lanes cover one key row, so a wave-instruction fetches 64/(D/8)
+// consecutive keys (1 KiB).  Every lane keeps an online-softmax stream (m, l, o[8]) for its
+// (key slot, d-chunk); the 4*64/(D/8) streams of a block are merged once through LDS.
+#include "common.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* Q, int64_t ldq,
+                                                           const unsigned short* Kc, const unsigned short* Vc,
+                                                           unsigned short* O, int64_t ldo, const int* lens,
+                                                           int n_heads, int max_len, float scale_log2e) {
+  constexpr int LPR = D / 8;     // lanes per key row
+  constexpr int KPW = 64 / LPR;  // keys per wave-instruction
+  constexpr int NSTREAM = 4 * KPW;
+  __shared__ float sm[NSTREAM][D + 2];  // per stream: o[D], m, l
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dc = lane % LPR, sub = lane / LPR;
+  const int len = min(lens[b], max_len);
+  const int64_t base = ((int64_t)b * n_heads + h) * (int64_t)max_len * D;
+  const unsigned short* kp = Kc + base + dc * 8;
+  const unsigned short* vp = Vc + base + dc * 8;
+
+  float q[8];
+  {
+    const u32x4 raw = *(const u32x4*)(Q + (int64_t)b * ldq + h * D + dc * 8);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      q[2 * t] = __uint_as_float(raw[t] << 16) * scale_log2e;
+      q[2 * t + 1] = __uint_as_float(raw[t] & 0xffff0000u) * scale_log2e;
+    }
+  }
+  float m = NEG_BIG, l = 0.f, o[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) o[t] = 0.f;
+
+  constexpr int UNR = 4;
+  for (int j0 = wave * KPW; j0 < len; j0 += 4 * KPW * UNR) {
+    u32x4 kr[UNR], vr[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int key = min(j0 + u * 4 * KPW + sub, len - 1);
+      kr[u] = *(const u32x4*)(kp + (int64_t)key * D);
+      vr[u] = *(const u32x4*)(vp + (int64_t)key * D);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int key = j0 + u * 4 * KPW + sub;
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s += q[2 * t] * __uint_as_float(kr[u][t] << 16);
+        s += q[2 * t + 1] * __uint_as_float(kr[u][t] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int x = 1; x < LPR; x <<= 1) s += __shfl_xor(s, x, 64);
+      const bool ok = key < len;
+      s = ok ? s : NEG_BIG;
+      const float m_new = fmaxf(m, s);
+      const float alpha = exp2f(m - m_new);
+      const float pe = ok ? exp2f(s - m_new) : 0.f;
+      m = m_new;
+      l = l * alpha + pe;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        o[2 * t] = o[2 * t] * alpha + pe * __uint_as_float(vr[u][t] << 16);
+        o[2 * t + 1] = o[2 * t + 1] * alpha + pe * __uint_as_float(vr[u][t] & 0xffff0000u);
+      }
+    }
+  }
+  const int stream = wave * KPW + sub;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) sm[stream][dc * 8 + t] = o[t];
+  if (dc == 0) {
+    sm[stream][D] = m;
+    sm[stream][D + 1] = l;
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const int d = threadIdx.x;
+    float M = NEG_BIG;
+#pragma unroll
+    for (int s = 0; s < NSTREAM; ++s) M = fmaxf(M, sm[s][D]);
+    float L = 0.f, acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSTREAM; ++s) {
+      const float w = exp2f(sm[s][D] - M);
+      L += sm[s][D + 1] * w;
+      acc += sm[s][d] * w;
+    }
+    O[(int64_t)b * ldo + h * D + d] = f32_to_bf16_bits(L > 0.f ? acc / L : 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int icl_attn_decode_bf16(const void* Q, int64_t ldq, const void* Kc, const void* Vc, void* O,
+                                    int64_t ldo, const int32_t* lens, int32_t n_seqs, int32_t n_heads,
+                                    int32_t head_dim, int32_t max_len, float scale, void* stream) {
+  ICL_CHECK_ARG(Q && Kc && Vc && O && lens, "icl_attn_decode_bf16: NULL pointer");
+  ICL_CHECK_ARG(head_dim == 64 || head_dim == 128, "icl_attn_decode_bf16: head_dim=%d (only 64 and 128)", head_dim);
+  ICL_CHECK_ARG(n_seqs > 0 && n_seqs <= 65535 && n_heads > 0 && max_len > 0, "icl_attn_decode_bf16: bad sizes");
+  ICL_CHECK_ARG(ldq % 8 == 0 && ((uintptr_t)Q & 15) == 0 && ((uintptr_t)Kc & 15) == 0 && ((uintptr_t)Vc & 15) == 0,
+                "icl_attn_decode_bf16: misaligned operands");
+  dim3 grid(n_heads, n_seqs);
+  if (head_dim == 64)
+    hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)Q,
+                       ldq, (const unsigned short*)Kc, (const unsigned short*)Vc, (unsigned short*)O, ldo, lens,
+                       n_heads, max_len, scale * LOG2E);
+  else
+    hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)Q,
+                       ldq, (const unsigned short*)Kc, (const unsigned short*)Vc, (unsigned short*)O, ldo, lens,
+                       n_heads, max_len, scale * LOG2E);
+  ICL_CHECK_LAUNCH("icl_attn_decode_bf16");
+  return ICL_OK;
+}

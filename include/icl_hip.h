@@ -1,0 +1,247 @@
+/*
+ * icl_hip.h — C-ABI of libicl_hip.so, the MI355X (gfx950 / CDNA4) kernel library behind the
+ * ICL forward/generate hot path of iiscleap/ICL-speech-text-LLM.
+ *
+ * The reference has NO FFI of its own: every kernel it runs is reached through PyTorch /
+ * transformers / the external SALMONN package.  Each entry point
+ * below therefore cites the reference call site (file:line under /root/reference) whose
+ * arithmetic it replaces, plus the implicit-op row of SURVEY.md §2.3 (K1..K14).
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; no torch types; every pointer is a DEVICE pointer unless
+ *     its name ends in _host;
+ *   - no allocation or ownership inside the library: the caller (PyTorch-ROCm on the host
+ *     side) allocates inputs, outputs and workspaces;
+ *   - every call is asynchronous w.r.t. the host and ordered on `stream` (a hipStream_t passed
+ *     as void*); nothing here synchronises, allocates or memcpy's, so every call may be
+ *     captured into a hipGraph;
+ *   - return value: 0 on success, a negative ICL_E* code otherwise; icl_last_error() returns
+ *     a thread-local, human-readable message for the most recent failure on this thread.
+ *     A failure never aborts the process and never leaves a kernel running: arguments are
+ *     validated on the host before any launch (reference behaviour to preserve: the per-batch
+ *     try/except in inference/inference.py:370-373 must be able to continue).
+ *   - "bf16" tensors are raw uint16 bit patterns of bfloat16; "f32" is IEEE binary32.
+ *   - all matrices are row-major with an explicit leading dimension (in ELEMENTS).
+ */
+#ifndef ICL_HIP_H
+#define ICL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICL_ABI_VERSION 1
+
+/* error codes */
+#define ICL_OK 0
+#define ICL_EINVAL (-1)  /* bad argument / unsupported shape (message in icl_last_error) */
+#define ICL_ELAUNCH (-2) /* hipLaunch / runtime error (message carries hipGetErrorString) */
+
+/* element types for outputs / residuals */
+#define ICL_BF16 0
+#define ICL_F32 1
+
+/* ---- library ------------------------------------------------------------------------- */
+int icl_abi_version(void);
+const char* icl_last_error(void);
+/* Number of compute units of the current device (used by callers to size split-K). */
+int icl_device_cu_count(void);
+
+/* ---- K2/K3/K5/K7/K8/K10/K13/K14: bf16 MFMA GEMM ----------------------------------------
+ * C[b][m][n] = epilogue( sum_k A[b][m][k] * W[n][k] )       (W is the PyTorch nn.Linear
+ * layout [N,K], K contiguous), fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+ * Replaces every nn.Linear / Conv1d-as-GEMM of the path: HF WhisperEncoder / LlamaForCausalLM
+ * reached from models/custom_salmon.py:550-554 (encode_speech) and :630-636 / :704-720
+ * (llama_model forward / generate).
+ *
+ * epilogue (applied in this order):  v = acc; v += bias[n] (ICL_EPI_BIAS);
+ *   v = gelu_erf(v) (ICL_EPI_GELU);  v = silu(v_gate)*v_up (ICL_EPI_SWIGLU, see below);
+ *   v += R[b][m][n] (ICL_EPI_RESIDUAL, R is f32 or bf16 per res_dtype); store as out_dtype.
+ * ICL_EPI_SWIGLU: W holds gate/up rows interleaved in blocks of 16 ([g0..g15,u0..u15,g16..]),
+ *   N counts the interleaved rows; the output has N/2 columns (ldc refers to that matrix).
+ * batch: independent problems on grid.z with element strides (stride 0 = broadcast; W has
+ *   no batch stride — the weight is shared).
+ * split_k > 1 (only with batch == 1): partial sums go to `workspace` (f32, at least
+ *   split_k*M*N elements) and a second kernel reduces them and applies the epilogue.
+ * Requirements: K % 64 == 0, lda/ldw % 8 == 0, A/W 16-byte aligned, N % 32 == 0 for SWIGLU.
+ */
+#define ICL_EPI_BIAS 1
+#define ICL_EPI_GELU 2
+#define ICL_EPI_RESIDUAL 4
+#define ICL_EPI_SWIGLU 8
+
+typedef struct icl_gemm_args {
+  const void* A;        /* bf16 [batch][M][lda]            */
+  const void* W;        /* bf16 [N][ldw]                   */
+  void* C;              /* out_dtype [batch][M][ldc]       */
+  const float* bias;    /* f32 [N] or NULL                 */
+  const void* R;        /* res_dtype [batch][M][ldr] or NULL */
+  float* workspace;     /* f32 split-K partials or NULL    */
+  int64_t lda, ldw, ldc, ldr;
+  int64_t strideA, strideC, strideR; /* batch strides in elements */
+  int32_t M, N, K;
+  int32_t batch;
+  int32_t epilogue;     /* OR of ICL_EPI_*                 */
+  int32_t out_dtype;    /* ICL_BF16 | ICL_F32              */
+  int32_t res_dtype;    /* ICL_BF16 | ICL_F32              */
+  int32_t split_k;      /* >= 1                            */
+  int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (skinny / decode), 3 = 256x256 */
+} icl_gemm_args;
+
+int icl_gemm_bf16(const icl_gemm_args* args, void* stream);
+
+/* ---- K3/K5/K10/K13/K14: fused (flash-style) attention forward ---------------------------
+ * O[t][h][:] = softmax_j( scale * Q[t][h]·K[j][h] + bias ) · V[j][h]   per packed sequence.
+ * Replaces the SDPA inside HF WhisperEncoderLayer / LlamaDecoderLayer / the BEATs
+ * MultiheadAttention (reached from models/custom_salmon.py:550-554 and :630-636/:704-720).
+ * Sequences are packed back to back: sequence s owns rows cu_seqlens[s] .. cu_seqlens[s+1]-1
+ * of Q, K, V and O (queries and keys share the packing: self-attention).
+ *   causal != 0   : key j visible to query i iff j <= i (positions relative to the sequence).
+ *   kv_lens       : optional int32 [n_seqs]; keys >= kv_lens[s] are masked (BEATs key padding
+ *                   mask; queries still run over the whole sequence).  Must be >= 1.
+ *   rel_bias      : optional f32 [n_heads][2*rel_span-1] table and rel_gate f32
+ *                   [total_rows][n_heads]: bias(i,j,h) = rel_gate[i][h] *
+ *                   rel_bias[h][clamp(j-i, -(rel_span-1), rel_span-1) + rel_span-1]
+ *                   (BEATs gated relative position bias, K5).
+ * head_dim must be 64 or 128.  Q/K/V row strides are in elements (so a fused QKV buffer can
+ * be addressed in place); head h lives at column h*head_dim of its row.
+ */
+typedef struct icl_attn_args {
+  const void* Q; const void* K; const void* V; /* bf16 */
+  void* O;                                     /* bf16 [total_rows][ldo] */
+  const int32_t* cu_seqlens;                   /* int32 [n_seqs+1] (device) */
+  const int32_t* kv_lens;                      /* int32 [n_seqs] or NULL (device) */
+  const float* rel_bias;                       /* f32 [n_heads][2*rel_span-1] or NULL */
+  const float* rel_gate;                       /* f32 [total_rows][n_heads] or NULL */
+  int64_t ldq, ldk, ldv, ldo;
+  int32_t n_seqs, max_seqlen, n_heads, head_dim;
+  int32_t causal, rel_span;
+  float scale;
+} icl_attn_args;
+
+int icl_attn_fwd_bf16(const icl_attn_args* args, void* stream);
+
+/* ---- K11: single-token decode attention over the KV cache --------------------------------
+ * One new query per sequence against cache rows [0, lens[b]) (the new token's K/V must
+ * already be in the cache).  Cache layout: [n_seqs][n_heads][max_len][head_dim] bf16.
+ * Replaces the cached-key SDPA inside HF GenerationMixin's greedy loop,
+ * models/custom_salmon.py:704-720.
+ */
+int icl_attn_decode_bf16(const void* Q, int64_t ldq, const void* Kc, const void* Vc, void* O,
+                         int64_t ldo, const int32_t* lens, int32_t n_seqs, int32_t n_heads,
+                         int32_t head_dim, int32_t max_len, float scale, void* stream);
+
+/* ---- K3/K5/K6/K7: LayerNorm;  K10/K14: RMSNorm -----------------------------------------
+ * LayerNorm: v = x[m][:] + (res ? alpha * res[m][:] : 0);
+ *            y[m][:] = (v - mean(v)) * rsqrt(var(v) + eps) * gamma + beta   (biased variance)
+ *   The optional pre-add is BEATs' deep-norm post-LN, LN(x + alpha*residual) (K5); res has
+ *   dtype in_dtype and leading dimension ldx.  y2 (optional, bf16, leading dimension ldy2)
+ *   receives a second copy of y: post-LN blocks (BEATs, Q-Former) keep the f32 stream in y
+ *   and feed the next GEMM from y2.
+ * RMSNorm:   y[m][:] = x[m][:] * rsqrt(mean(x^2) + eps) * gamma
+ * x is f32 or bf16 (in_dtype), y bf16 or f32 (out_dtype); gamma/beta f32; all math in f32;
+ * N % 4 == 0 and N <= 8192.
+ * Replaces nn.LayerNorm / LlamaRMSNorm in the HF / SALMONN modules (models/custom_salmon.py
+ * :550-554, :630-636) incl. SALMONN's ln_speech / ln_audio (K6).
+ */
+int icl_layernorm(const void* x, int64_t ldx, const void* res, float alpha, const float* gamma,
+                  const float* beta, void* y, int64_t ldy, void* y2, int64_t ldy2, int32_t M,
+                  int32_t N, float eps, int32_t in_dtype, int32_t out_dtype, void* stream);
+int icl_rmsnorm(const void* x, int64_t ldx, const float* gamma, void* y, int64_t ldy, int32_t M,
+                int32_t N, float eps, int32_t in_dtype, int32_t out_dtype, void* stream);
+
+/* ---- K10/K11/K14: rotary embedding + KV-cache append -------------------------------------
+ * In place on the q and k column blocks of a fused bf16 QKV buffer [M][ld] (q at column 0,
+ * k at column k_off, v at column v_off; n_heads x head_dim each; HF "rotate_half" pairing
+ * (i, i+head_dim/2)); cos/sin f32 [max_pos][head_dim/2].  Row m belongs to sequence seq_ids[m]
+ * at position pos[m].  If kcache != NULL the rotated k and the v row are also written to the
+ * cache ([n_seqs][n_heads][max_len][head_dim]) at row pos[m] of sequence seq_ids[m].
+ * Replaces LlamaRotaryEmbedding/apply_rotary_pos_emb + DynamicCache.update of transformers,
+ * reached from models/custom_salmon.py:630-636 / :704-720.
+ */
+int icl_rope_kv_bf16(void* qkv, int64_t ld, int64_t k_off, int64_t v_off, const float* cos,
+                     const float* sin, const int32_t* pos, const int32_t* seq_ids, void* kcache,
+                     void* vcache, int32_t M, int32_t n_heads, int32_t head_dim, int32_t max_len,
+                     void* stream);
+
+/* ---- K9: token-embedding gather + speech interleave --------------------------------------
+ * out[r][:] = src_idx[r] >= 0 ? table[src_idx[r]][:] : speech[-src_idx[r]-1][:]
+ * table bf16 [vocab][H]; speech f32 [n_speech_rows][H]; out f32 [rows][H].
+ * Replaces embed_tokens + torch.cat interleave of models/custom_salmon.py:189-194, :243-283.
+ */
+int icl_embed_gather_interleave(const int32_t* src_idx, const void* table, const float* speech,
+                                float* out, int32_t rows, int32_t H, int32_t vocab,
+                                int32_t n_speech_rows, void* stream);
+
+/* ---- K11: greedy argmax + EOS/pad bookkeeping --------------------------------------------
+ * tok = finished[b] ? pad_id : argmax_v logits[b][v] (lowest index on ties);
+ * finished[b] |= (tok == eos_id); out_tokens[b*out_stride + step] = tok; next_ids[b] = tok.
+ * Replaces HF GenerationMixin._sample greedy branch (models/custom_salmon.py:704-720).
+ */
+int icl_argmax_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, int32_t eos_id,
+                   int32_t pad_id, int32_t* finished, int32_t* out_tokens, int32_t out_stride,
+                   int32_t step, int32_t* next_ids, void* stream);
+
+/* ---- K1: Whisper log-mel (f64 STFT, f32 out) ---------------------------------------------
+ * wav f32 [n_audio][wav_ld] with valid lengths wav_lens (device int32; samples past the length
+ * or past 480000 are treated as zero), -> spec f32 [n_audio][80][3000] (n_mel x 3000) and,
+ * if xt != NULL, the conv-stem operand bf16 [n_audio][3002][xt_ld] (time-major, rows 0 and
+ * 3001 zero, columns >= n_mel zero).  n_fft=400, hop=160, periodic Hann, reflect-padded
+ * centre frames, Slaney mel filters `mel_filters` f64 [n_mel][201], log10, max-8 clamp,
+ * (x+4)/4 — WhisperFeatureExtractor semantics (data/model_processors.py:641-645, :659-663).
+ * workspace: f32 [n_audio][n_mel][3000] + int32 [n_audio] (raw log10 values + per-audio max).
+ */
+int icl_logmel_whisper(const float* wav, int64_t wav_ld, const int32_t* wav_lens,
+                       const double* mel_filters, int32_t n_mel, int32_t n_audio, float* spec,
+                       void* xt, int64_t xt_ld, void* workspace, void* stream);
+/* spec f32 [n_audio][n_mel][3000] -> conv-stem operand xt (same layout as above). */
+int icl_spec_to_xt(const float* spec, int32_t n_mel, int32_t n_audio, void* xt, int64_t xt_ld,
+                   void* stream);
+
+/* ---- K4: BEATs front-end: Kaldi fbank (f64 math, f32 out) ---------------------------------
+ * wav (f32, scaled by 2^15 inside) -> fbank f32 [n_audio][max_frames][128]:
+ * 25 ms / 10 ms frames (snip_edges), DC removal, pre-emphasis 0.97, povey window, 512-pt
+ * power spectrum, 128 Kaldi mel bins (`mel_banks` f64 [128][257]), log(max(x, FLT_EPSILON)),
+ * then (x - mean) / (2*std).  Frames >= n_frames(len) are written as the value the reference
+ * produces for zero-padded audio only when `wav` itself holds those zeros; rows past
+ * max_frames are not touched.  torchaudio.compliance.kaldi.fbank semantics as used by
+ * BEATs.preprocess (external SALMONN package; call site models/custom_salmon.py:412-416).
+ */
+int icl_fbank_kaldi(const float* wav, int64_t wav_ld, const int32_t* wav_lens,
+                    const double* mel_banks, int32_t n_audio, int32_t max_frames, float mean,
+                    float std, float* fbank, void* stream);
+
+/* ---- K7: window-level Q-Former cross attention (1 query x win keys) ------------------------
+ * q bf16 [n_win][ldq] (n_heads x 64), kv bf16 [n_audio*rows_per_audio][ldkv] with K at
+ * column 0 and V at column v_off; window w of audio a covers rows a*rows_per_audio + w*win
+ * .. +win-1 (SALMONN's F.unfold with kernel == stride is a free view).
+ * out bf16 [n_win][ldo].  Replaces BertSelfAttention(cross) of SALMONN's speech_Qformer
+ * (call site models/custom_salmon.py:550-554).
+ */
+int icl_qformer_window_xattn(const void* q, int64_t ldq, const void* kv, int64_t ldkv,
+                             int64_t v_off, void* out, int64_t ldo, int32_t n_audio,
+                             int32_t win_per_audio, int32_t win, int32_t rows_per_audio,
+                             int32_t n_heads, float scale, void* stream);
+
+/* ---- small fused element-wise helpers ----------------------------------------------------- */
+/* BEATs gate (K5): from the fused bf16 QKV rows (q block = first n_heads*64 columns, WITH
+ * bias, unscaled), gate[m][h] = ga*(gb*grep_a[h]-1)+2 where (ga,gb) =
+ * sigmoid(sum4(grep_w[8][64]·q_h + grep_b[8])).  Output f32 [M][n_heads]. */
+int icl_beats_gate(const void* qkv, int64_t ld, const float* grep_w, const float* grep_b,
+                   const float* grep_a, float* gate, int32_t M, int32_t n_heads, void* stream);
+/* y = x (+ y_in) with dtype conversion: out[m][n] = (float)in[m][n] * alpha (+ add[m][n]) */
+int icl_axpby_cast(const void* in, int64_t ldi, int32_t in_dtype, const void* add, int64_t lda_,
+                   int32_t add_dtype, float alpha, void* out, int64_t ldo, int32_t out_dtype,
+                   int32_t M, int32_t N, void* stream);
+/* LoRA down-projection written into the K-augmentation columns of the GEMM operand:
+ * X[m][K0 + j] = bf16( scale * sum_k X[m][k] * A[j][k] ), j < r_total; A bf16 [r_total][lda_].
+ * (peft LoRA restated: W x + (alpha/r) B (A x); models/custom_salmon.py:78-81 config.) */
+int icl_lora_down_bf16(void* X, int64_t ldx, int32_t K0, const void* A, int64_t lda_,
+                       int32_t r_total, float scale, int32_t M, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICL_HIP_H */

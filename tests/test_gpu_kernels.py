@@ -1,0 +1,431 @@
+"""Parity of every libicl_hip kernel against a plain PyTorch fp32 reference of the same op
+(`-m gpu`; all calls go through the C-ABI via runtime/binding.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def B():
+    import icl_speech_text_llm_amd.runtime.binding as b
+    b.load_library()
+    return b
+
+
+def _rand_bf16(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+def _relerr(got, ref):
+    got, ref = got.float(), ref.float()
+    return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [
+    (128, 128, 64), (256, 384, 128), (300, 200, 192), (1, 64, 64), (33, 4096, 4096 // 8), (1500, 1280, 1280),
+    (376, 4096, 4096), (88, 768, 3072), (17, 48, 6144),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_plain(B, M, N, K, tile):
+    a, w = _rand_bf16(M, K, seed=1), _rand_bf16(N, K, seed=2)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    B.gemm(a, w, out, tile=tile)
+    ref = a.float() @ w.float().t()
+    torch.cuda.synchronize()
+    err = (out - ref).abs().max().item()
+    assert err <= 1e-3 * math.sqrt(K), (err, M, N, K)
+    assert _relerr(out, ref) < 1e-5
+
+
+def test_gemm_identity_asymmetric(B):
+    # A = I with an asymmetric W catches a transposed C write (guide §3)
+    K = 128
+    a = torch.eye(K, dtype=torch.bfloat16, device=DEV)
+    w = (torch.arange(256 * K, device=DEV).reshape(256, K) % 251).to(torch.bfloat16)
+    out = torch.empty(K, 256, dtype=torch.float32, device=DEV)
+    B.gemm(a, w, out)
+    assert torch.equal(out, w.float().t())
+
+
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_epilogues(B, tile):
+    M, N, K = 200, 256, 256
+    a, w = _rand_bf16(M, K, seed=3, scale=0.5), _rand_bf16(N, K, seed=4, scale=0.1)
+    bias = torch.randn(N, device=DEV)
+    res32 = torch.randn(M, N, device=DEV)
+    res16 = _rand_bf16(M, N, seed=5)
+    base = a.float() @ w.float().t()
+    # bias + gelu -> bf16
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    B.gemm(a, w, out, bias=bias, gelu=True, tile=tile)
+    ref = torch.nn.functional.gelu(base + bias)
+    assert (out.float() - ref).abs().max().item() <= 2e-2 and _relerr(out, ref) < 4e-3
+    # bias + f32 residual -> f32 (in place on the residual stream)
+    stream = res32.clone()
+    B.gemm(a, w, stream, bias=bias, residual=stream, tile=tile)
+    assert (stream - (base + bias + res32)).abs().max().item() <= 1e-3
+    # bf16 residual -> bf16
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    B.gemm(a, w, out, residual=res16, tile=tile)
+    ref = base + res16.float()
+    assert _relerr(out, ref) < 4e-3
+    # gelu then residual (Whisper conv2 + positional embedding order)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    B.gemm(a, w, out, bias=bias, gelu=True, residual=res32, tile=tile)
+    ref = torch.nn.functional.gelu(base + bias) + res32
+    assert (out - ref).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("split_k", [1, 4])
+def test_gemm_swiglu(B, tile, split_k):
+    M, I, K = 70, 11008 // 8, 512
+    a = _rand_bf16(M, K, seed=6, scale=0.5)
+    wg, wu = _rand_bf16(I, K, seed=7, scale=0.1), _rand_bf16(I, K, seed=8, scale=0.1)
+    # interleave gate/up rows in blocks of 16
+    w = torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+    out = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(split_k * M * 2 * I, dtype=torch.float32, device=DEV) if split_k > 1 else None
+    B.gemm(a, w, out, swiglu=True, tile=tile, split_k=split_k, workspace=ws)
+    ref = torch.nn.functional.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
+    assert _relerr(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize("M", [1, 16, 32, 64])
+@pytest.mark.parametrize("split_k", [2, 8])
+def test_gemm_splitk_decode_shapes(B, M, split_k):
+    N, K = 1024, 4096
+    a, w = _rand_bf16(M, K, seed=9, scale=0.5), _rand_bf16(N, K, seed=10, scale=0.05)
+    bias = torch.randn(N, device=DEV)
+    res = torch.randn(M, N, device=DEV)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ws = torch.empty(split_k * M * N, dtype=torch.float32, device=DEV)
+    B.gemm(a, w, out, bias=bias, residual=res, split_k=split_k, workspace=ws, tile=2)
+    ref = a.float() @ w.float().t() + bias + res
+    assert (out - ref).abs().max().item() <= 2e-3
+
+
+def test_gemm_odd_n_unaligned_ldc(B):
+    # lm_head: N = 32001, ldc = 32001 (rows not 16-byte aligned -> scalar store path)
+    M, N, K = 5, 32001, 256
+    a, w = _rand_bf16(M, K, seed=11), _rand_bf16(N, K, seed=12, scale=0.05)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    B.gemm(a, w, out)
+    ref = a.float() @ w.float().t()
+    assert (out - ref).abs().max().item() <= 1e-3
+
+
+def test_gemm_conv_as_strided_gemm(B):
+    # Whisper conv2 (k=3, stride 2, pad 1) as a GEMM over a time-major padded operand with lda = 2*C
+    Bn, T, C, Co = 2, 60, 64, 128
+    x = _rand_bf16(Bn, T, C, seed=13)                       # [B, T, C] time-major
+    wconv = _rand_bf16(Co, C, 3, seed=14, scale=0.1)        # torch Conv1d weight [Co, Ci, k]
+    xp = torch.zeros(Bn, T + 2, C, dtype=torch.bfloat16, device=DEV)
+    xp[:, 1:T + 1] = x
+    wk = wconv.permute(0, 2, 1).reshape(Co, 3 * C).contiguous()   # [Co, k*C]
+    Tout = T // 2
+    out = torch.empty(Bn, Tout, Co, dtype=torch.float32, device=DEV)
+    B.gemm(xp, wk, out, M=Tout, K=3 * C, lda=2 * C, batch=Bn, stride_a=(T + 2) * C, stride_c=Tout * Co)
+    ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), wconv.float(), stride=2, padding=1).transpose(1, 2)
+    assert (out - ref).abs().max().item() <= 2e-3
+
+
+def test_gemm_rejects_bad_args(B):
+    a, w = _rand_bf16(8, 96), _rand_bf16(8, 96)
+    out = torch.empty(8, 8, dtype=torch.float32, device=DEV)
+    with pytest.raises(B.IclError, match="multiple of 64"):
+        B.gemm(a, w, out)
+    # the library stays usable after an error
+    a, w = _rand_bf16(8, 64), _rand_bf16(8, 64)
+    B.gemm(a, w, out)
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, cu, H, D, scale, causal=False, kv_lens=None, rel_bias=None, rel_gate=None, rel_span=0):
+    out = torch.zeros(q.shape[0], H * D, dtype=torch.float32, device=q.device)
+    for s in range(len(cu) - 1):
+        a, b = cu[s], cu[s + 1]
+        L = b - a
+        qs = q[a:b].float().view(L, H, D).transpose(0, 1)
+        ks = k[a:b].float().view(L, H, D).transpose(0, 1)
+        vs = v[a:b].float().view(L, H, D).transpose(0, 1)
+        sc = qs @ ks.transpose(1, 2) * scale
+        i = torch.arange(L, device=q.device)
+        if rel_bias is not None:
+            rel = (i[None, :] - i[:, None]).clamp(-(rel_span - 1), rel_span - 1) + rel_span - 1
+            sc = sc + rel_gate[a:b].t()[:, :, None] * rel_bias[:, rel]
+        mask = torch.zeros(L, L, dtype=torch.bool, device=q.device)
+        if causal:
+            mask |= i[None, :] > i[:, None]
+        if kv_lens is not None:
+            mask |= (i >= kv_lens[s])[None, :]
+        sc = sc.masked_fill(mask[None], float("-inf"))
+        o = torch.softmax(sc, dim=-1) @ vs
+        out[a:b] = o.transpose(0, 1).reshape(L, H * D)
+    return out
+
+
+@pytest.mark.parametrize("D,H", [(64, 3), (128, 2)])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("lens", [[128], [1], [200, 64, 377], [1500]])
+def test_attn_fwd(B, D, H, causal, lens):
+    total = sum(lens)
+    cu = [0]
+    for L in lens:
+        cu.append(cu[-1] + L)
+    qkv = _rand_bf16(total, 3 * H * D, seed=21)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    out = torch.full((total, H * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    scale = D ** -0.5
+    B.attn_fwd(q, k, v, out, cu_t, max(lens), H, D, scale, causal=causal)
+    ref = _attn_ref(q, k, v, cu, H, D, scale, causal=causal)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2, err
+    assert _relerr(out, ref) < 1e-2
+
+
+def test_attn_fwd_kv_lens_and_spike(B):
+    # key padding + a spiked key that forces the online-softmax rescale late in the sequence
+    D, H, lens = 64, 2, [300, 130]
+    total = sum(lens)
+    cu = [0, 300, 430]
+    q, k, v = _rand_bf16(total, H * D, seed=22), _rand_bf16(total, H * D, seed=23), _rand_bf16(total, H * D, seed=24)
+    k[250] = (q[10].float() * 4).to(torch.bfloat16)   # huge score for query 10 at key 250 (4th KV tile)
+    kv = torch.tensor([260, 100], dtype=torch.int32, device=DEV)
+    out = torch.empty(total, H * D, dtype=torch.bfloat16, device=DEV)
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    B.attn_fwd(q, k, v, out, cu_t, 300, H, D, 0.125, kv_lens=kv)
+    ref = _attn_ref(q, k, v, cu, H, D, 0.125, kv_lens=[260, 100])
+    assert (out.float() - ref).abs().max().item() <= 2e-2
+
+
+def test_attn_fwd_rel_bias(B):
+    D, H, lens, span = 64, 4, [333, 90], 333
+    total = sum(lens)
+    cu = [0, 333, 423]
+    q, k, v = _rand_bf16(total, H * D, seed=25), _rand_bf16(total, H * D, seed=26), _rand_bf16(total, H * D, seed=27)
+    rel_bias = torch.randn(H, 2 * span - 1, device=DEV)
+    rel_gate = torch.rand(total, H, device=DEV) * 2
+    out = torch.empty(total, H * D, dtype=torch.bfloat16, device=DEV)
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    B.attn_fwd(q, k, v, out, cu_t, 333, H, D, 0.125, rel_bias=rel_bias, rel_gate=rel_gate, rel_span=span)
+    ref = _attn_ref(q, k, v, cu, H, D, 0.125, rel_bias=rel_bias, rel_gate=rel_gate, rel_span=span)
+    assert (out.float() - ref).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("D,H", [(128, 4), (64, 6)])
+def test_attn_decode(B, D, H):
+    Bn, max_len = 5, 400
+    lens = torch.tensor([1, 7, 64, 377, 400], dtype=torch.int32, device=DEV)
+    q = _rand_bf16(Bn, H * D, seed=31)
+    kc, vc = _rand_bf16(Bn, H, max_len, D, seed=32), _rand_bf16(Bn, H, max_len, D, seed=33)
+    out = torch.empty(Bn, H * D, dtype=torch.bfloat16, device=DEV)
+    B.attn_decode(q, kc, vc, out, lens, H, D, max_len, D ** -0.5)
+    for b in range(Bn):
+        L = int(lens[b])
+        sc = torch.einsum("hd,hld->hl", q[b].float().view(H, D), kc[b, :, :L].float()) * D ** -0.5
+        ref = torch.einsum("hl,hld->hd", torch.softmax(sc, -1), vc[b, :, :L].float()).reshape(-1)
+        assert (out[b].float() - ref).abs().max().item() <= 1e-2
+
+
+# ------------------------------------------------------------------------------------------------
+# norms / element-wise
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [768, 1280, 2048, 4096, 5120])
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16])
+def test_layernorm(B, N, in_dtype):
+    M = 37
+    x = (torch.randn(M, N, device=DEV) * 3 + 1).to(in_dtype)
+    g, b = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    out2 = torch.empty(M, N + 8, dtype=torch.bfloat16, device=DEV)
+    B.layernorm(x, g, b, out, 1e-5, out2=out2, N=N)
+    ref = torch.nn.functional.layer_norm(x.float(), (N,), g, b, 1e-5)
+    assert (out - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
+    assert torch.equal(out2[:, :N], out.to(torch.bfloat16))
+    # deep-norm pre-add
+    res = torch.randn(M, N, device=DEV).to(in_dtype)
+    B.layernorm(x, g, b, out, 1e-5, res=res, alpha=1.7)
+    ref = torch.nn.functional.layer_norm(x.float() + 1.7 * res.float(), (N,), g, b, 1e-5)
+    assert (out - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("N", [4096, 5120])
+def test_rmsnorm(B, N):
+    M = 19
+    x = torch.randn(M, N, device=DEV) * 2
+    g = torch.randn(N, device=DEV)
+    out = torch.empty(M, N + 64, dtype=torch.bfloat16, device=DEV)
+    B.rmsnorm(x, g, out, 1e-5, N=N)
+    ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * g
+    assert torch.equal(out[:, :N], ref.to(torch.bfloat16)) or (out[:, :N].float() - ref).abs().max().item() <= 4e-2
+    assert _relerr(out[:, :N], ref) < 3e-3
+
+
+def test_rope_kv(B):
+    H, D, M, max_len, nseq = 4, 128, 11, 32, 3
+    qkv = _rand_bf16(M, 3 * H * D, seed=41)
+    orig = qkv.clone()
+    pos = torch.tensor([0, 1, 2, 3, 0, 1, 5, 6, 7, 30, 31], dtype=torch.int32, device=DEV)
+    sid = torch.tensor([0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 2], dtype=torch.int32, device=DEV)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2, device=DEV).float() / D))
+    ang = torch.arange(max_len, device=DEV).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    kc = torch.zeros(nseq, H, max_len, D, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    B.rope_kv(qkv, H * D, 2 * H * D, cos, sin, pos, sid, kc, vc, H, D, max_len)
+
+    def rot(x):  # x [M, H, D] f32
+        c, s = cos[pos.long()][:, None, :], sin[pos.long()][:, None, :]
+        x1, x2 = x[..., :D // 2], x[..., D // 2:]
+        return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1)
+
+    qr = rot(orig[:, :H * D].float().view(M, H, D)).to(torch.bfloat16)
+    kr = rot(orig[:, H * D:2 * H * D].float().view(M, H, D)).to(torch.bfloat16)
+    assert torch.equal(qkv[:, :H * D].view(M, H, D), qr)
+    assert torch.equal(qkv[:, H * D:2 * H * D].view(M, H, D), kr)
+    assert torch.equal(qkv[:, 2 * H * D:], orig[:, 2 * H * D:])
+    for m in range(M):
+        assert torch.equal(kc[sid[m], :, pos[m]], kr[m])
+        assert torch.equal(vc[sid[m], :, pos[m]], orig[m, 2 * H * D:].view(H, D))
+
+
+def test_embed_gather_interleave(B):
+    V, Hd = 300, 512
+    table = _rand_bf16(V, Hd, seed=42)
+    speech = torch.randn(20, Hd, device=DEV)
+    idx = torch.tensor([5, 299, -1, -20, 0, 17, -3], dtype=torch.int32, device=DEV)
+    out = torch.empty(7, Hd, dtype=torch.float32, device=DEV)
+    B.embed_gather_interleave(idx, table, speech, out)
+    for r, i in enumerate(idx.tolist()):
+        ref = table[i].float() if i >= 0 else speech[-i - 1]
+        assert torch.equal(out[r], ref)
+
+
+def test_argmax_eos(B):
+    Bn, V = 4, 32001
+    logits = torch.randn(Bn, V, device=DEV)
+    logits[0, 123] = 50.0
+    logits[1, 2] = 50.0            # EOS
+    logits[2, 7] = 50.0
+    logits[2, 9000] = 50.0         # tie -> lowest index
+    logits[3, 32000] = 50.0
+    fin = torch.tensor([0, 0, 0, 1], dtype=torch.int32, device=DEV)
+    toks = torch.full((Bn, 10), -1, dtype=torch.int32, device=DEV)
+    nxt = torch.empty(Bn, dtype=torch.int32, device=DEV)
+    B.argmax_eos(logits, 2, 32000, fin, toks, 3, nxt)
+    assert toks[:, 3].tolist() == [123, 2, 7, 32000]
+    assert nxt.tolist() == [123, 2, 7, 32000]
+    assert fin.tolist() == [0, 1, 0, 1]
+    assert (toks[:, :3] == -1).all()
+
+
+def test_lora_down(B):
+    M, K0, r = 9, 4096, 16
+    x = _rand_bf16(M, K0 + 64, seed=43)
+    x[:, K0:] = 0
+    a = _rand_bf16(r, K0, seed=44, scale=0.05)
+    ref = (x[:, :K0].float() @ a.float().t() * 2.0)
+    B.lora_down(x, K0, a, r, 2.0)
+    assert _relerr(x[:, K0:K0 + r], ref) < 4e-3
+    assert (x[:, K0 + r:] == 0).all()
+
+
+def test_beats_gate(B):
+    M, H = 50, 12
+    qkv = _rand_bf16(M, 3 * H * 64, seed=45)
+    gw, gb, ga = torch.randn(8, 64, device=DEV) * 0.2, torch.randn(8, device=DEV), torch.rand(H, device=DEV) + 0.5
+    gate = torch.empty(M, H, dtype=torch.float32, device=DEV)
+    B.beats_gate(qkv, gw, gb, ga, gate, H)
+    qh = qkv[:, :H * 64].float().view(M, H, 64)
+    proj = (qh @ gw.t() + gb).view(M, H, 2, 4).sum(-1)
+    ga_, gb_ = torch.sigmoid(proj[..., 0]), torch.sigmoid(proj[..., 1])
+    ref = ga_ * (gb_ * ga[None, :] - 1.0) + 2.0
+    assert (gate - ref).abs().max().item() <= 1e-4
+
+
+def test_qformer_window_xattn(B):
+    n_audio, wpa, win, rpa, H = 2, 88, 17, 1500, 12
+    q = _rand_bf16(n_audio * wpa, H * 64, seed=46)
+    kv = _rand_bf16(n_audio * rpa, 2 * H * 64, seed=47)
+    out = torch.empty(n_audio * wpa, H * 64, dtype=torch.bfloat16, device=DEV)
+    B.qformer_window_xattn(q, kv, H * 64, out, n_audio, wpa, win, rpa, H, 0.125)
+    k = kv[:, :H * 64].float().view(n_audio, rpa, H, 64)[:, :wpa * win].reshape(n_audio * wpa, win, H, 64)
+    v = kv[:, H * 64:].float().view(n_audio, rpa, H, 64)[:, :wpa * win].reshape(n_audio * wpa, win, H, 64)
+    sc = torch.einsum("whd,wjhd->whj", q.float().view(-1, H, 64), k) * 0.125
+    ref = torch.einsum("whj,wjhd->whd", torch.softmax(sc, -1), v).reshape(n_audio * wpa, H * 64)
+    assert (out.float() - ref).abs().max().item() <= 1e-2
+
+
+def test_axpby_cast(B):
+    x = torch.randn(13, 70, device=DEV)
+    add = _rand_bf16(13, 70, seed=48)
+    out = torch.empty(13, 70, dtype=torch.bfloat16, device=DEV)
+    B.axpby_cast(x, out, alpha=0.5, add=add)
+    assert torch.equal(out, (x * 0.5 + add.float()).to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------
+# audio front-ends vs the numpy oracle
+# ------------------------------------------------------------------------------------------------
+def test_logmel_whisper(B):
+    from oracle import audio_frontend as af
+    lens = [8000, 116800, 480000]
+    wav = torch.zeros(3, 480000, dtype=torch.float32)
+    for i, L in enumerate(lens):
+        rng = np.random.default_rng(1234 + i)
+        wav[i, :L] = torch.from_numpy(np.clip(rng.normal(0, 0.1, L), -1, 1).astype(np.float32))
+    wav_d = wav.to(DEV)
+    wl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    mel = torch.from_numpy(af.slaney_mel_filters(80)).to(DEV)
+    spec = torch.empty(3, 80, 3000, dtype=torch.float32, device=DEV)
+    xt = torch.full((3, 3002, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(3 * 80 * 3000 + 3, dtype=torch.float32, device=DEV)
+    B.logmel_whisper(wav_d, wl, mel, 80, spec, xt, ws)
+    for i, L in enumerate(lens):
+        ref = torch.from_numpy(af.whisper_logmel(wav[i, :L].numpy()))
+        err = (spec[i].cpu() - ref).abs().max().item()
+        assert err <= 1e-4, (i, err)
+    assert (xt[:, 0] == 0).all() and (xt[:, 3001] == 0).all() and (xt[:, :, 80:] == 0).all()
+    assert torch.equal(xt[:, 1:3001, :80], spec.transpose(1, 2).to(torch.bfloat16))
+    xt2 = torch.empty_like(xt)
+    B.spec_to_xt(spec, xt2)
+    assert torch.equal(xt, xt2)
+
+
+def test_fbank_kaldi(B):
+    from oracle import audio_frontend as af
+    lens = [399 + 160 * 5 + 7, 48000, 480000]
+    wav = torch.zeros(3, 480000, dtype=torch.float32)
+    for i, L in enumerate(lens):
+        rng = np.random.default_rng(77 + i)
+        wav[i, :L] = torch.from_numpy(np.clip(rng.normal(0, 0.1, L), -1, 1).astype(np.float32))
+    wl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    banks = torch.from_numpy(af.kaldi_mel_banks()).to(DEV)
+    max_frames = af.kaldi_num_frames(480000)
+    out = torch.full((3, max_frames, 128), float("nan"), dtype=torch.float32, device=DEV)
+    B.fbank_kaldi(wav.to(DEV), wl, banks, max_frames, af.FBANK_MEAN, af.FBANK_STD, out)
+    for i, L in enumerate(lens):
+        ref = torch.from_numpy(af.kaldi_fbank(wav[i, :L].numpy()))
+        nf = ref.shape[0]
+        assert nf == af.kaldi_num_frames(L)
+        err = (out[i, :nf].cpu() - ref).abs().max().item()
+        assert err <= 1e-4, (i, err)
+        assert torch.isnan(out[i, nf:]).all()
