@@ -362,3 +362,66 @@ extern "C" int icl_qformer_window_xattn(const void* q, int64_t ldq, const void* 
   ICL_CHECK_LAUNCH("icl_qformer_window_xattn");
   return ICL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// K12: shift-by-one causal-LM cross entropy (HF LlamaForCausalLM loss, ignore_index = -100).
+// Row r of `logits` predicts labels[r] (the caller passes labels already shifted); one block per row.
+namespace {
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* logits, int64_t ldl, const int* labels, int V,
+                                                       float* row_loss) {
+  __shared__ float red[4];
+  const int64_t r = blockIdx.x;
+  const int y = labels[r];
+  if (y < 0 || y >= V) {
+    if (threadIdx.x == 0) row_loss[r] = 0.f;
+    return;
+  }
+  const float* row = logits + r * ldl;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, row[v]);
+  mx = wave_reduce_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) s += __expf(row[v] - mx);
+  s = wave_reduce_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) row_loss[r] = logf(red[0] + red[1] + red[2] + red[3]) + mx - row[y];
+}
+__global__ __launch_bounds__(256) void ce_mean_kernel(const float* row_loss, const int* labels, int V, int M, float* out) {
+  __shared__ float rs[4];
+  __shared__ float rc[4];
+  float s = 0.f, c = 0.f;
+  for (int r = threadIdx.x; r < M; r += blockDim.x) {
+    const int y = labels[r];
+    if (y >= 0 && y < V) {
+      s += row_loss[r];
+      c += 1.f;
+    }
+  }
+  s = wave_reduce_sum(s);
+  c = wave_reduce_sum(c);
+  if ((threadIdx.x & 63) == 0) {
+    rs[threadIdx.x >> 6] = s;
+    rc[threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float S = rs[0] + rs[1] + rs[2] + rs[3], C = rc[0] + rc[1] + rc[2] + rc[3];
+    out[0] = C > 0.f ? S / C : nanf("");
+  }
+}
+}  // namespace
+
+extern "C" int icl_cross_entropy(const float* logits, int64_t ldl, const int32_t* labels, int32_t M, int32_t V,
+                                 float* row_loss, float* mean_loss, void* stream) {
+  ICL_CHECK_ARG(logits && labels && row_loss && mean_loss && M > 0 && V > 0 && ldl >= V, "icl_cross_entropy: bad arguments");
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ldl, labels, V, row_loss);
+  ICL_CHECK_LAUNCH("icl_cross_entropy(rows)");
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)row_loss, labels, V, M, mean_loss);
+  ICL_CHECK_LAUNCH("icl_cross_entropy(mean)");
+  return ICL_OK;
+}

@@ -78,6 +78,11 @@ _SIGNATURES = {
                                c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "icl_lora_down_bf16": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_float, c_int32,
                                    c_void_p]),
+    "icl_beats_patchify": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "icl_beats_posconv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                       c_void_p]),
+    "icl_gather_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "icl_cross_entropy": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -314,3 +319,34 @@ def lora_down(x, K0: int, a, r_total: int, scale: float, M=None):
 
 def device_cu_count() -> int:
     return load_library().icl_device_cu_count()
+
+
+def beats_patchify(fbank, cu_rows, total_rows: int, out):
+    _require_gpu(fbank, cu_rows, out)
+    _check(load_library().icl_beats_patchify(fbank.data_ptr(), fbank.shape[1], cu_rows.data_ptr(), fbank.shape[0],
+                                             total_rows, out.data_ptr(), _stream()), "icl_beats_patchify")
+
+
+def beats_posconv_pack(x, cu_rows, valid_rows, n_audio: int, total_rows: int, groups: int, xg):
+    _require_gpu(x, cu_rows, valid_rows, xg)
+    _check(load_library().icl_beats_posconv_pack(x.data_ptr(), cu_rows.data_ptr(), valid_rows.data_ptr(), n_audio,
+                                                 total_rows, x.shape[1], groups, xg.data_ptr(), _stream()),
+           "icl_beats_posconv_pack")
+
+
+def gather_rows(src, idx, out, N=None):
+    _require_gpu(src, idx, out)
+    assert src.dtype == torch.float32 and out.dtype == torch.float32 and idx.dtype == torch.int32
+    _check(load_library().icl_gather_rows_f32(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(),
+                                              out.stride(0), idx.numel(), src.shape[1] if N is None else N,
+                                              _stream()), "icl_gather_rows_f32")
+    return out
+
+
+def cross_entropy(logits, labels, row_loss, mean_loss, V=None):
+    _require_gpu(logits, labels, row_loss, mean_loss)
+    assert logits.dtype == torch.float32 and labels.dtype == torch.int32
+    _check(load_library().icl_cross_entropy(logits.data_ptr(), logits.stride(0), labels.data_ptr(), labels.numel(),
+                                            logits.shape[1] if V is None else V, row_loss.data_ptr(),
+                                            mean_loss.data_ptr(), _stream()), "icl_cross_entropy")
+    return mean_loss

@@ -1,0 +1,379 @@
+"""Kernel chains of the ICL hot path: each engine strings libicl_hip entry points together over
+buffers that stay resident in HBM (allocated once per shape through ``Workspace``; PyTorch is used
+for memory and streams only — every arithmetic step below is a C-ABI call).
+
+Stages:  K1 log-mel -> K2/K3 Whisper encoder ‖ K4/K5 BEATs -> K6 LN+concat ->
+K7 window Q-Former -> K8 projector -> K9 embedding interleave -> K10 Llama prefill -> K11 decode.
+Reference call sites: models/custom_salmon.py:546-554 (encode_speech), :115-299 (prompt wrap),
+:556-640 (forward), :642-739 (generate_output).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import binding as B
+from .packing import PackedBeats, PackedLlama, PackedQFormer, PackedWhisper
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+class Workspace:
+    """Named device buffers keyed by (name, shape, dtype); reused across calls so the steady-state
+    loop performs no allocation (and decode graphs can capture stable pointers)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._bufs: Dict[tuple, torch.Tensor] = {}
+
+    def get(self, name: str, shape: Sequence[int], dtype, zero: bool = False) -> torch.Tensor:
+        key = (name, tuple(int(s) for s in shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
+
+
+def _i32(x, device) -> torch.Tensor:
+    return torch.as_tensor(x, dtype=I32).to(device, non_blocking=True)
+
+
+# ================================================================================================
+# K1: log-mel + conv-stem operand
+# ================================================================================================
+class LogMel:
+    def __init__(self, n_mels: int, device):
+        # Slaney filter bank, f64 [n_mels, 201] (restated in runtime/audio_tables.py; data, not arithmetic)
+        from .audio_tables import slaney_mel_filters
+        self.n_mels = n_mels
+        self.device = torch.device(device)
+        self.filters = torch.from_numpy(slaney_mel_filters(n_mels)).to(self.device)
+
+    def __call__(self, ws: Workspace, wav: torch.Tensor, wav_lens: torch.Tensor, want_spec: bool = False):
+        """wav f32 [n, L] (device), wav_lens int32 [n] -> (xt bf16 [n, 3002, 128], spec f32 [n, n_mels, 3000] | None)"""
+        n = wav.shape[0]
+        xt = ws.get("logmel_xt", (n, 3002, 128), BF16)
+        spec = ws.get("logmel_spec", (n, self.n_mels, 3000), F32) if want_spec else None
+        scratch = ws.get("logmel_ws", (n * self.n_mels * 3000 + n,), F32)
+        B.logmel_whisper(wav, wav_lens, self.filters, self.n_mels, spec, xt, scratch)
+        return xt, spec
+
+    def from_spectrogram(self, ws: Workspace, spec: torch.Tensor) -> torch.Tensor:
+        n = spec.shape[0]
+        xt = ws.get("logmel_xt", (n, 3002, 128), BF16)
+        B.spec_to_xt(spec.contiguous(), xt)
+        return xt
+
+
+# ================================================================================================
+# K2 + K3: Whisper encoder
+# ================================================================================================
+class WhisperEncoderHIP:
+    def __init__(self, w: PackedWhisper):
+        self.w = w
+
+    def forward(self, ws: Workspace, xt: torch.Tensor) -> torch.Tensor:
+        """xt bf16 [n, 3002, 128] -> final-LayerNorm output f32 [n*1500, d]."""
+        w, c = self.w, self.w.cfg
+        n, d, T = xt.shape[0], c.d_model, c.n_ctx
+        M = n * T
+        x2 = ws.get("wh_x2", (n, 3002, d), BF16, zero=True)      # conv1 output, rows 0 / 3001 stay zero
+        h = ws.get("wh_h", (M, d), F32)
+        xn = ws.get("wh_xn", (M, d), BF16)
+        qkv = ws.get("wh_qkv", (M, 3 * d), BF16)
+        att = ws.get("wh_att", (M, d), BF16)
+        ff = ws.get("wh_ff", (M, c.ffn), BF16)
+        out = ws.get("wh_out", (M, d), F32)
+        cu = ws.get("wh_cu", (n + 1,), I32)
+        cu.copy_(torch.arange(0, M + 1, T, dtype=I32), non_blocking=True)
+        # conv1 (k=3,p=1) as GEMM over the time-major padded mel: row t = xt[t:t+3, :128] (K = 384)
+        B.gemm(xt, w.conv1_w, x2[:, 1:], bias=w.conv1_b, gelu=True, M=3000, K=384, lda=128, batch=n,
+               stride_a=3002 * 128, stride_c=3002 * d)
+        # conv2 (k=3,s=2,p=1): row t = x2[2t:2t+3, :] (lda = 2d, K = 3d), + GELU, + positional embedding
+        B.gemm(x2, w.conv2_w, h, bias=w.conv2_b, gelu=True, residual=w.pos, M=T, K=3 * d, lda=2 * d, batch=n,
+               stride_a=3002 * d, stride_c=T * d, stride_r=0)
+        D = d // c.n_heads
+        for L in w.layers:
+            B.layernorm(h, L.ln1_g, L.ln1_b, xn, 1e-5)
+            B.gemm(xn, L.wqkv, qkv, bias=L.bqkv)
+            B.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, cu, T, c.n_heads, D, D ** -0.5)
+            B.gemm(att, L.wo, h, bias=L.bo, residual=h)
+            B.layernorm(h, L.ln2_g, L.ln2_b, xn, 1e-5)
+            B.gemm(xn, L.w1, ff, bias=L.b1, gelu=True)
+            B.gemm(ff, L.w2, h, bias=L.b2, residual=h)
+        B.layernorm(h, w.lnf_g, w.lnf_b, out, 1e-5)
+        return out
+
+
+# ================================================================================================
+# K4 + K5: BEATs
+# ================================================================================================
+class BeatsHIP:
+    def __init__(self, w: PackedBeats, device):
+        from .audio_tables import kaldi_mel_banks
+        self.w = w
+        self.banks = torch.from_numpy(kaldi_mel_banks()).to(device)
+
+    @staticmethod
+    def frames(n_samples: int) -> int:
+        return 0 if n_samples < 400 else 1 + (n_samples - 400) // 160
+
+    @classmethod
+    def tokens(cls, n_samples: int) -> int:
+        return (cls.frames(n_samples) // 16) * 8
+
+    def forward(self, ws: Workspace, wav: torch.Tensor, padded_lens: List[int], valid_lens: List[int]):
+        """wav f32 [n, L] zero padded.  Audio a is processed over padded_lens[a] samples (what the reference's
+        BEATs sees: the collated, padded waveform) with keys/rows beyond valid_lens[a] masked.
+        Returns (x f32 [sum T_a, d] packed, cu (host list), T list)."""
+        w, c = self.w, self.w.cfg
+        dev = wav.device
+        n, d = wav.shape[0], c.d_model
+        nf = [self.frames(L) for L in padded_lens]
+        T = [(f // 16) * 8 for f in nf]
+        assert min(T) > 0, "audio shorter than one BEATs patch (16 frames)"
+        assert max(T) <= w.rel_span, "audio longer than the packed relative-position span"
+        cu_h = [0]
+        for t in T:
+            cu_h.append(cu_h[-1] + t)
+        M = cu_h[-1]
+        # valid token count per audio: BEATs.forward_padding_mask applied twice (frames, then patches)
+        valid_T = []
+        for a in range(n):
+            vf = self._valid_units(valid_lens[a], padded_lens[a], nf[a])
+            valid_T.append(max(1, self._valid_units(vf, nf[a], T[a])))
+        max_frames = max(nf)
+        fb = ws.get("be_fbank", (n, max_frames, 128), F32)
+        B.fbank_kaldi(wav, _i32(padded_lens, dev), self.banks, max_frames, c.fbank_mean, c.fbank_std, fb)
+        cu = _i32(cu_h, dev)
+        valid = _i32(valid_T, dev)
+        patches = ws.get("be_patches", (M, 256), BF16)
+        B.beats_patchify(fb, cu, M, patches)
+        e = ws.get("be_e", (M, c.embed), F32)
+        eb = ws.get("be_eb", (M, c.embed), BF16)
+        B.gemm(patches, w.patch_w, e)
+        B.layernorm(e, w.ln0_g, w.ln0_b, eb, 1e-5)
+        x = ws.get("be_x", (M, d), F32)
+        B.gemm(eb, w.proj_w, x, bias=w.proj_b)
+        # positional grouped conv as 16 GEMMs per audio over the padded per-group image
+        G, cpg = c.conv_groups, d // c.conv_groups
+        xg = ws.get("be_xg", ((M + 128 * n) * d,), BF16)
+        B.beats_posconv_pack(x, cu, valid, n, M, G, xg)
+        y = ws.get("be_y", (M, d), F32)
+        uniform = all(t == T[0] for t in T)
+        for g in range(G):
+            wg, bg = w.posconv_w[g], w.posconv_b[g * cpg:(g + 1) * cpg]
+            if uniform:
+                a_view = xg[g * (T[0] + 128) * cpg:]
+                B.gemm(a_view, wg, y[:, g * cpg:], bias=bg, gelu=True, residual=x[:, g * cpg:], M=T[0], K=128 * cpg,
+                       lda=cpg, batch=n, stride_a=(T[0] + 128) * d, stride_c=T[0] * d, stride_r=T[0] * d)
+            else:
+                for a in range(n):
+                    base = (cu_h[a] + 128 * a) * d + g * (T[a] + 128) * cpg
+                    B.gemm(xg[base:], wg, y[cu_h[a]:cu_h[a + 1], g * cpg:], bias=bg, gelu=True,
+                           residual=x[cu_h[a]:cu_h[a + 1], g * cpg:], M=T[a], K=128 * cpg, lda=cpg)
+        xb = ws.get("be_xb", (M, d), BF16)
+        B.layernorm(y, w.enc_ln_g, w.enc_ln_b, x, 1e-5, out2=xb)
+        qkv = ws.get("be_qkv", (M, 3 * d), BF16)
+        att = ws.get("be_att", (M, d), BF16)
+        o = ws.get("be_o", (M, d), F32)
+        ff = ws.get("be_ff", (M, c.ffn), BF16)
+        gate = ws.get("be_gate", (M, c.n_heads), F32)
+        alpha = c.deep_norm_alpha
+        for L in w.layers:
+            B.gemm(xb, L.wqkv, qkv, bias=L.bqkv)
+            B.beats_gate(qkv, L.extra["grep_w"], L.extra["grep_b"], L.extra["grep_a"], gate, c.n_heads)
+            B.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, cu, max(T), c.n_heads, 64, 0.125,
+                       kv_lens=valid, rel_bias=w.rel_table, rel_gate=gate, rel_span=w.rel_span)
+            B.gemm(att, L.wo, o, bias=L.bo)
+            B.layernorm(o, L.ln1_g, L.ln1_b, x, 1e-5, res=x, alpha=alpha, out2=xb)   # LN(alpha*x + attn)
+            B.gemm(xb, L.w1, ff, bias=L.b1, gelu=True)
+            B.gemm(ff, L.w2, o, bias=L.b2)
+            B.layernorm(o, L.ln2_g, L.ln2_b, x, 1e-5, res=x, alpha=alpha, out2=xb)
+        return x, cu_h, T
+
+    @staticmethod
+    def _valid_units(valid_in: int, total_in: int, n_units: int) -> int:
+        """Number of leading units NOT fully padded under BEATs.forward_padding_mask: the mask over `total_in`
+        inputs is trimmed to a multiple of n_units and a unit is padding iff ALL its inputs are padding."""
+        if n_units == 0:
+            return 0
+        per = total_in // n_units
+        if per == 0:
+            return n_units
+        return min(n_units, -(-valid_in // per)) if valid_in > 0 else 0
+
+
+# ================================================================================================
+# K6 + K7 + K8: LN + concat, window-level Q-Former, projector
+# ================================================================================================
+class SpeechQFormerHIP:
+    def __init__(self, w: PackedQFormer, whisper_d: int, beats_d: int, llm_hidden: int):
+        self.w, self.whisper_d, self.beats_d, self.llm_hidden = w, whisper_d, beats_d, llm_hidden
+        c = w.cfg
+        self.win = round(1500 * c.second_per_window / 30.0)
+        self.stride = round(1500 * c.second_stride / 30.0)
+        assert self.win == self.stride, "HIP path implements non-overlapping windows (kernel == stride, SURVEY.md A8)"
+
+    def n_windows(self, T: int = 1500) -> int:
+        return (T - self.win) // self.stride + 1
+
+    def forward(self, ws: Workspace, speech: torch.Tensor, n: int, audio: Optional[torch.Tensor] = None,
+                audio_cu: Optional[List[int]] = None) -> torch.Tensor:
+        """speech f32 [n*1500, dw] (Whisper out), audio f32 [sum T_a, db] packed (BEATs out) -> f32 [n*88, H_llm]."""
+        w, c = self.w, self.w.cfg
+        T, dw, db, hq = 1500, self.whisper_d, self.beats_d, c.hidden
+        C = dw + (db if audio is not None else 0)
+        assert C == c.enc_width, f"Q-Former encoder width {c.enc_width} != {C}"
+        cat = ws.get("qf_cat", (n * T, C), BF16)
+        B.layernorm(speech, w.ln_speech_g, w.ln_speech_b, cat, 1e-5, N=dw)
+        if audio is not None:
+            cat[:, dw:].zero_()   # F.pad of the shorter BEATs stream (memset; rows past T_a stay zero)
+            for a in range(n):
+                ta = min(audio_cu[a + 1] - audio_cu[a], T)
+                B.layernorm(audio[audio_cu[a]:audio_cu[a] + ta], w.ln_audio_g, w.ln_audio_b,
+                            cat[a * T:a * T + ta, dw:], 1e-5, N=db)
+        nw = self.n_windows(T)
+        W = n * nw
+        h = ws.get("qf_h", (W, hq), F32)
+        hb = ws.get("qf_hb", (W, hq), BF16)
+        t32 = ws.get("qf_t32", (W, hq), F32)
+        tb = ws.get("qf_tb", (W, hq), BF16)
+        q = ws.get("qf_q", (W, hq), BF16)
+        kv = ws.get("qf_kv", (n * T, 2 * hq), BF16)
+        ff = ws.get("qf_ff", (W, c.ffn), BF16)
+        # query token -> embeddings.LayerNorm, broadcast to every window (row stride 0 source)
+        q0 = ws.get("qf_q0", (1, hq), F32)
+        B.layernorm(w.query, w.emb_ln_g, w.emb_ln_b, q0, c.ln_eps)
+        B.axpby_cast(q0.expand(W, hq), h)
+        B.axpby_cast(q0.expand(W, hq), hb)
+        for L in w.layers:
+            # self-attention over ONE token: softmax == 1, context = value projection
+            B.gemm(hb, L.sa_wv, tb, bias=L.sa_bv)
+            B.gemm(tb, L.sa_wo, t32, bias=L.sa_bo, residual=h)
+            B.layernorm(t32, L.sa_ln_g, L.sa_ln_b, h, c.ln_eps, out2=hb)
+            # cross-attention: 1 query x 17 window frames
+            B.gemm(hb, L.ca_wq, q, bias=L.ca_bq)
+            B.gemm(cat, L.ca_wkv, kv, bias=L.ca_bkv)
+            B.qformer_window_xattn(q, kv, hq, tb, n, nw, self.win, T, c.n_heads, 0.125)
+            B.gemm(tb, L.ca_wo, t32, bias=L.ca_bo, residual=h)
+            B.layernorm(t32, L.ca_ln_g, L.ca_ln_b, h, c.ln_eps, out2=hb)
+            # query feed-forward
+            B.gemm(hb, L.w1, ff, bias=L.b1, gelu=True)
+            B.gemm(ff, L.w2, t32, bias=L.b2, residual=h)
+            B.layernorm(t32, L.ff_ln_g, L.ff_ln_b, h, c.ln_eps, out2=hb)
+        out = ws.get("qf_out", (W, self.llm_hidden), F32)
+        B.gemm(hb, w.proj_w, out, bias=w.proj_b)
+        return out
+
+
+# ================================================================================================
+# K9 + K10 + K11 (+K12 host side): Llama
+# ================================================================================================
+class LlamaHIP:
+    def __init__(self, w: PackedLlama, device):
+        self.w = w
+        self.device = torch.device(device)
+        self.n_cu = max(B.device_cu_count(), 1)
+
+    # ---- K9 ------------------------------------------------------------------------------------
+    def embed(self, ws: Workspace, src_idx: torch.Tensor, speech: Optional[torch.Tensor], name: str = "ll_h") -> torch.Tensor:
+        h = ws.get(name, (src_idx.numel(), self.w.cfg.hidden), F32)
+        B.embed_gather_interleave(src_idx, self.w.embed, speech, h)
+        return h
+
+    # ---- one decoder layer over M packed rows ---------------------------------------------------
+    def _layer(self, ws: Workspace, L, h, M: int, tag: str, attn_fn, pos, seq_ids, kc, vc, max_len: int,
+               split: Optional[dict] = None):
+        c, w = self.w.cfg, self.w
+        hd, I, D, H = c.hidden, c.ffn, c.head_dim, c.n_heads
+        xn = ws.get(tag + "xn", (M, w.k_aug), BF16, zero=True)   # augmentation tail stays zero
+        qkv = ws.get(tag + "qkv", (M, 3 * hd), BF16)
+        att = ws.get(tag + "att", (M, hd), BF16)
+        act = ws.get(tag + "act", (M, I), BF16)
+        sk = split or {}
+        wsk = ws.get(tag + "splitk", (max(sk.values()) * M * max(3 * hd, 2 * I),), F32) if sk else None
+        B.rmsnorm(h, L.rms1, xn, c.rms_eps, N=hd)
+        if L.lora_a is not None:
+            B.lora_down(xn, hd, L.lora_a, 2 * c.lora_rank, c.lora_scale, M=M)
+        B.gemm(xn, L.wqkv, qkv, split_k=sk.get("qkv", 1), workspace=wsk, tile=sk.get("tile", 0))
+        B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
+        attn_fn(qkv, att)
+        B.gemm(att, L.wo, h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=sk.get("tile", 0))
+        B.rmsnorm(h, L.rms2, xn, c.rms_eps, N=hd)
+        B.gemm(xn, L.wgu, act, swiglu=True, K=hd, split_k=sk.get("gu", 1), workspace=wsk, tile=sk.get("tile", 0))
+        B.gemm(act, L.wdown, h, residual=h, split_k=sk.get("down", 1), workspace=wsk, tile=sk.get("tile", 0))
+
+    # ---- K10: prefill over ragged packed sequences ------------------------------------------------
+    def prefill(self, ws: Workspace, h: torch.Tensor, seq_lens: List[int], cache: Optional["KVCache"] = None) -> torch.Tensor:
+        """h f32 [sum S_b, hidden] (modified in place) -> same buffer holding the final hidden states."""
+        c = self.w.cfg
+        dev = h.device
+        M = sum(seq_lens)
+        cu_h = [0]
+        for s in seq_lens:
+            cu_h.append(cu_h[-1] + s)
+        assert max(seq_lens) <= c.max_pos
+        pos = _i32([p for s in seq_lens for p in range(s)], dev)
+        sid = _i32([b for b, s in enumerate(seq_lens) for _ in range(s)], dev)
+        cu = _i32(cu_h, dev)
+        maxS = max(seq_lens)
+        H, D, hd = c.n_heads, c.head_dim, c.hidden
+
+        def attn(qkv, att):
+            B.attn_fwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], att, cu, maxS, H, D, D ** -0.5, causal=True)
+
+        for i, L in enumerate(self.w.layers):
+            kc = cache.k[i] if cache is not None else None
+            vc = cache.v[i] if cache is not None else None
+            self._layer(ws, L, h, M, "pf_", attn, pos, sid, kc, vc, cache.max_len if cache is not None else 0)
+        return h
+
+    def logits(self, ws: Workspace, h_rows: torch.Tensor, name: str = "ll_logits") -> torch.Tensor:
+        """h_rows f32 [R, hidden] -> logits f32 [R, vocab] (final RMSNorm + lm_head)."""
+        c = self.w.cfg
+        R = h_rows.shape[0]
+        xn = ws.get(name + "_xn", (R, c.hidden), BF16)
+        out = ws.get(name, (R, c.vocab), F32)
+        B.rmsnorm(h_rows, self.w.norm, xn, c.rms_eps)
+        B.gemm(xn, self.w.lm_head, out)
+        return out
+
+    # ---- K11: one decode step for Bn sequences -----------------------------------------------------
+    def decode_step(self, ws: Workspace, cache: "KVCache", next_ids: torch.Tensor, pos: torch.Tensor,
+                    lens: torch.Tensor, sid: torch.Tensor) -> torch.Tensor:
+        c = self.w.cfg
+        Bn = next_ids.numel()
+        h = self.embed(ws, next_ids, None, name="dc_h")
+        H, D = c.n_heads, c.head_dim
+        # split-K so that every GEMM of the step launches >= ~2 blocks per CU (weights are streamed once)
+        def sk(N, K):
+            tiles = ((N + 63) // 64) * ((Bn + 63) // 64)
+            s = max(1, min(K // 512, (2 * self.n_cu + tiles - 1) // tiles))
+            return min(s, 16)
+        split = dict(qkv=sk(3 * c.hidden, self.w.k_aug), o=sk(c.hidden, c.hidden), gu=sk(2 * c.ffn, c.hidden),
+                     down=sk(c.hidden, c.ffn), tile=2)
+
+        for i, L in enumerate(self.w.layers):
+            kc, vc = cache.k[i], cache.v[i]
+
+            def attn(qkv, att, kc=kc, vc=vc):
+                B.attn_decode(qkv[:, :c.hidden], kc, vc, att, lens, H, D, cache.max_len, D ** -0.5)
+
+            self._layer(ws, L, h, Bn, "dc_", attn, pos, sid, kc, vc, cache.max_len, split=split)
+        return self.logits(ws, h, name="dc_logits")
+
+
+class KVCache:
+    """bf16 K/V cache, per layer [n_seqs][n_heads][max_len][head_dim] (one contiguous stream per (seq, head))."""
+
+    def __init__(self, cfg, n_seqs: int, max_len: int, device):
+        self.n_seqs, self.max_len = n_seqs, max_len
+        shape = (cfg.n_layers, n_seqs, cfg.n_heads, max_len, cfg.head_dim)
+        self.k = torch.empty(shape, dtype=BF16, device=device)
+        self.v = torch.empty(shape, dtype=BF16, device=device)

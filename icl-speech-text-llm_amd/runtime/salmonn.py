@@ -1,0 +1,212 @@
+"""SalmonnRuntime — the MI355X-native stand-in for the external ``SALMONN.models.salmonn_org.SALMONN``
+object that the reference builds at models/custom_salmon.py:96 and drives through
+``encode_speech`` (:550), ``llama_model(...)`` (:631) and ``llama_model.generate(...)`` (:705).
+
+It owns the packed weights (HBM resident, bf16), one ``Workspace`` of activation buffers and the four
+kernel chains of runtime/engines.py.  Prompts arrive as *segments* (token-id runs and speech-row runs)
+so that the string work of ``custom_prompt_wrap`` stays on the host while the interleave itself is one
+gather kernel (K9).  Everything arithmetic goes through libicl_hip; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import binding as B
+from .config import SalmonnCfg
+from .engines import BF16, F32, I32, BeatsHIP, KVCache, LlamaHIP, LogMel, SpeechQFormerHIP, WhisperEncoderHIP, Workspace, _i32
+from .packing import normalize_keys, pack_beats, pack_llama, pack_qformer, pack_whisper
+
+Segment = Union[Sequence[int], Tuple[str, int, int]]  # token ids | ("speech", first_row, n_rows)
+
+
+def speech_segment(first_row: int, n_rows: int) -> Tuple[str, int, int]:
+    return ("speech", first_row, n_rows)
+
+
+@dataclass
+class GenerateResult:
+    tokens: torch.Tensor          # int64 [B, width] on CPU — what HF generate() returns with inputs_embeds
+    first_logits: Optional[torch.Tensor] = None  # f32 [B, V] (device) logits of the first generated position
+
+
+class SalmonnRuntime:
+    def __init__(self, cfg: SalmonnCfg, state_dict: Dict[str, torch.Tensor], device="cuda", consume: bool = False,
+                 parts: Sequence[str] = ("whisper", "beats", "qformer", "llama")):
+        if not torch.cuda.is_available():
+            raise B.IclError("SalmonnRuntime needs a GPU: the HIP path has no CPU fallback")
+        B.load_library()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        sd = normalize_keys(state_dict) if not consume else state_dict
+        self.ws = Workspace(self.device)
+        self.whisper = self.beats = self.qformer = self.llama = None
+        if "whisper" in parts:
+            self.logmel = LogMel(cfg.whisper.n_mels, self.device)
+            self.whisper = WhisperEncoderHIP(pack_whisper(sd, cfg.whisper, self.device, consume=consume))
+        if "beats" in parts and cfg.beats is not None:
+            self.beats = BeatsHIP(pack_beats(sd, cfg.beats, self.device, consume=consume), self.device)
+        if "qformer" in parts:
+            self.qformer = SpeechQFormerHIP(pack_qformer(sd, cfg.qformer, self.device, consume=consume),
+                                            cfg.whisper.d_model, cfg.beats.d_model if self.beats is not None else 0,
+                                            cfg.llama.hidden)
+        if "llama" in parts:
+            self.llama = LlamaHIP(pack_llama(sd, cfg.llama, self.device, consume=consume), self.device)
+        self._caches: Dict[tuple, KVCache] = {}
+
+    # --------------------------------------------------------------------------------------------
+    # K1-K8: SALMONN.encode_speech
+    # --------------------------------------------------------------------------------------------
+    @property
+    def tokens_per_audio(self) -> int:
+        return self.qformer.n_windows(1500)
+
+    def encode_speech(self, raw_wav: Optional[torch.Tensor], wav_lens: Optional[Sequence[int]] = None,
+                      spectrogram: Optional[torch.Tensor] = None, padded_lens: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """raw_wav f32 [n, L] (zero padded; host or device), wav_lens valid samples per audio.
+        spectrogram (optional, f32 [n, n_mels, 3000]): use the caller's log-mel instead of K1.
+        padded_lens: length the reference's BEATs would see per audio (defaults to wav_lens: batch-1 semantics).
+        Returns speech embeddings f32 [n, 88, H_llm] on the device (atts are all ones in the reference)."""
+        ws, dev = self.ws, self.device
+        if raw_wav is not None:
+            raw_wav = raw_wav.to(device=dev, dtype=F32)
+            if raw_wav.dim() == 1:
+                raw_wav = raw_wav[None]
+            raw_wav = raw_wav.contiguous()
+            n = raw_wav.shape[0]
+            if wav_lens is None:
+                wav_lens = [raw_wav.shape[1]] * n
+            wav_lens = [int(x) for x in wav_lens]
+        else:
+            n = spectrogram.shape[0]
+        if spectrogram is not None:
+            xt = self.logmel.from_spectrogram(ws, spectrogram.to(device=dev, dtype=F32))
+        else:
+            xt, _ = self.logmel(ws, raw_wav, _i32(wav_lens, dev))
+        speech = self.whisper.forward(ws, xt)
+        audio = cu = None
+        if self.beats is not None and raw_wav is not None:
+            padded = [int(x) for x in (padded_lens if padded_lens is not None else wav_lens)]
+            audio, cu, _ = self.beats.forward(ws, raw_wav, padded, wav_lens)
+        out = self.qformer.forward(ws, speech, n, audio, cu)
+        return out.view(n, self.tokens_per_audio, self.cfg.llama.hidden)
+
+    def log_mel(self, raw_wav: torch.Tensor, wav_lens: Sequence[int]) -> torch.Tensor:
+        """K1 alone: f32 [n, n_mels, 3000] (the ``spectrogram`` batch key of the reference's processor)."""
+        raw_wav = raw_wav.to(device=self.device, dtype=F32).contiguous()
+        _, spec = self.logmel(self.ws, raw_wav, _i32([int(x) for x in wav_lens], self.device), want_spec=True)
+        return spec
+
+    # --------------------------------------------------------------------------------------------
+    # K9: prompt segments -> gather indices
+    # --------------------------------------------------------------------------------------------
+    def _gather_indices(self, prompts: Sequence[Sequence[Segment]], n_speech_rows: int) -> Tuple[List[int], List[int]]:
+        V = self.cfg.llama.vocab
+        flat: List[int] = []
+        lens: List[int] = []
+        for segs in prompts:
+            before = len(flat)
+            for seg in segs:
+                if isinstance(seg, tuple) and len(seg) == 3 and seg[0] == "speech":
+                    _, first, cnt = seg
+                    if first < 0 or first + cnt > n_speech_rows:
+                        raise ValueError(f"speech segment [{first},{first + cnt}) outside {n_speech_rows} speech rows")
+                    flat.extend(-(r + 1) for r in range(first, first + cnt))
+                else:
+                    for t in seg:
+                        t = int(t)
+                        if not 0 <= t < V:
+                            raise ValueError(f"token id {t} outside the vocabulary [0,{V})")
+                        flat.append(t)
+            if len(flat) == before:
+                raise ValueError("empty prompt")
+            lens.append(len(flat) - before)
+        return flat, lens
+
+    def embed_prompts(self, prompts, speech: Optional[torch.Tensor], name: str = "ll_h"):
+        rows = 0 if speech is None else speech.shape[0] * (speech.shape[1] if speech.dim() == 3 else 1)
+        sp2 = None if speech is None else speech.reshape(rows, self.cfg.llama.hidden).contiguous()
+        flat, lens = self._gather_indices(prompts, rows)
+        h = self.llama.embed(self.ws, _i32(flat, self.device), sp2, name=name)
+        return h, lens
+
+    # --------------------------------------------------------------------------------------------
+    # K10 (+K12): teacher-forced forward
+    # --------------------------------------------------------------------------------------------
+    def forward_logits(self, prompts, speech: Optional[torch.Tensor]) -> Tuple[torch.Tensor, List[int]]:
+        """All-position logits f32 [sum S_b, V] (packed) and the per-sequence lengths."""
+        h, lens = self.embed_prompts(prompts, speech, name="fw_h")
+        self.llama.prefill(self.ws, h, lens, cache=None)
+        return self.llama.logits(self.ws, h, name="fw_logits"), lens
+
+    def cross_entropy(self, logits: torch.Tensor, shifted_labels: torch.Tensor) -> torch.Tensor:
+        """mean CE over rows with label >= 0; logits f32 [M, V] (device), shifted_labels int32 [M]."""
+        M = logits.shape[0]
+        rows = self.ws.get("ce_rows", (M,), F32)
+        mean = self.ws.get("ce_mean", (1,), F32)
+        B.cross_entropy(logits, shifted_labels.to(device=self.device, dtype=I32), rows, mean)
+        return mean
+
+    # --------------------------------------------------------------------------------------------
+    # K10 + K11: greedy generate
+    # --------------------------------------------------------------------------------------------
+    def _cache(self, n_seqs: int, max_len: int) -> KVCache:
+        key = (n_seqs, max_len)
+        c = self._caches.get(key)
+        if c is None:
+            if len(self._caches) > 4:
+                self._caches.clear()
+            c = self._caches[key] = KVCache(self.cfg.llama, n_seqs, max_len, self.device)
+        return c
+
+    def generate(self, prompts, speech: Optional[torch.Tensor], max_new_tokens: int = 10, eos_id: Optional[int] = None,
+                 pad_id: Optional[int] = None, suppress_eos: bool = False, want_first_logits: bool = False,
+                 cache_len_multiple: int = 64) -> GenerateResult:
+        """Greedy search with HF ``generate(inputs_embeds=…)`` semantics (models/custom_salmon.py:704-720): returns only
+        the new tokens; a row that has emitted EOS is filled with pad; the width is that of the longest row
+        (``min_length`` is a no-op with inputs_embeds).  All steps are enqueued without a host sync; the
+        early-stop width is applied on the host afterwards (identical output, no per-token round trip)."""
+        c, ws, dev = self.cfg.llama, self.ws, self.device
+        eos = c.eos_id if eos_id is None else eos_id
+        pad = c.pad_id if pad_id is None else pad_id
+        if suppress_eos:
+            eos = -1  # benchmark mode: exactly max_new_tokens per row
+        assert max_new_tokens >= 1
+        h, lens = self.embed_prompts(prompts, speech)
+        Bn = len(lens)
+        need = max(lens) + max_new_tokens
+        max_len = -(-need // cache_len_multiple) * cache_len_multiple
+        assert max_len <= c.max_pos, f"prompt + new tokens ({need}) exceeds max_pos {c.max_pos}"
+        cache = self._cache(Bn, max_len)
+        self.llama.prefill(ws, h, lens, cache)
+        cu_last = []
+        acc = 0
+        for s in lens:
+            acc += s
+            cu_last.append(acc - 1)
+        last = ws.get("gen_last", (Bn, c.hidden), F32)
+        B.gather_rows(h, _i32(cu_last, dev), last)
+        logits = self.llama.logits(ws, last, name="gen_logits")
+        first = logits.clone() if want_first_logits else None
+        finished = ws.get("gen_finished", (Bn,), I32)
+        finished.zero_()
+        toks = ws.get("gen_tokens", (Bn, max_new_tokens), I32)
+        nxt = ws.get("gen_next", (Bn,), I32)
+        B.argmax_eos(logits, eos, pad, finished, toks, 0, nxt)
+        if max_new_tokens > 1:
+            steps = max_new_tokens - 1
+            pos_all = _i32([[s + t for s in lens] for t in range(steps)], dev)          # position of the fed token
+            len_all = _i32([[s + t + 1 for s in lens] for t in range(steps)], dev)      # cache length after append
+            sid = _i32(list(range(Bn)), dev)
+            for t in range(steps):
+                lg = self.llama.decode_step(ws, cache, nxt, pos_all[t], len_all[t], sid)
+                B.argmax_eos(lg, eos, pad, finished, toks, t + 1, nxt)
+        out = toks.cpu().to(torch.int64)                                                 # the only D2H of the call
+        width = max_new_tokens
+        if eos >= 0:
+            is_eos = out == eos
+            first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((Bn,), max_new_tokens))
+            width = int(first_eos.max())
+        return GenerateResult(tokens=out[:, :width].contiguous(), first_logits=first)

@@ -241,6 +241,34 @@ int icl_axpby_cast(const void* in, int64_t ldi, int32_t in_dtype, const void* ad
 int icl_lora_down_bf16(void* X, int64_t ldx, int32_t K0, const void* A, int64_t lda_,
                        int32_t r_total, float scale, int32_t M, void* stream);
 
+/* ---- K4/K5: BEATs data movers (so both BEATs convolutions run on icl_gemm_bf16) ----------------
+ * icl_beats_patchify: fbank f32 [n_audio][max_frames][128] -> im2col of Conv2d(1->512, k=16, s=16):
+ *   out bf16 [total_rows][256], packed row cu_rows[a] + t'*8 + f', column i*16 + j =
+ *   fbank[a][16t'+i][16f'+j]  (BEATs.patch_embedding; external SALMONN package, call site
+ *   models/custom_salmon.py:412-416).
+ * icl_beats_posconv_pack: x f32 [total_rows][channels] (packed by cu_rows; BEATs: 768 channels, 16 groups).  Rows >= valid_rows[a] of
+ *   audio a are zeroed in place (backbone `x[padding_mask] = 0`), and xg (bf16) receives per audio
+ *   the image [groups][T_a + 128][channels/groups] with 64 zero rows in front / 64 behind, located at
+ *   element offset (cu_rows[a] + 128*a)*channels: row t of group g then sees the 128x48 taps of
+ *   Conv1d(768,768,k=128,pad=64,groups=16) as ONE contiguous K = 6144 run (lda = 48).
+ * icl_gather_rows_f32: out[r][:] = src[idx[r]][:]  (last-token rows for the LM head).
+ */
+int icl_beats_patchify(const float* fbank, int32_t max_frames, const int32_t* cu_rows, int32_t n_audio,
+                       int32_t total_rows, void* out, void* stream);
+int icl_beats_posconv_pack(float* x, const int32_t* cu_rows, const int32_t* valid_rows, int32_t n_audio,
+                           int32_t total_rows, int32_t channels, int32_t groups, void* xg, void* stream);
+int icl_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, float* out, int64_t ld_out,
+                        int32_t rows, int32_t N, void* stream);
+
+/* ---- K12: causal-LM cross entropy (teacher-forced forward only) -------------------------------
+ * row_loss[r] = logsumexp(logits[r][:]) - logits[r][labels[r]] for labels[r] in [0,V), else 0;
+ * mean_loss[0] = mean of row_loss over the valid rows (NaN if none) — torch CrossEntropyLoss with
+ * ignore_index=-100, reduction='mean'.  The caller passes row r = position t of a sequence together
+ * with labels[r] = label of position t+1 (HF shift-by-one; models/custom_salmon.py:617-640).
+ */
+int icl_cross_entropy(const float* logits, int64_t ldl, const int32_t* labels, int32_t M, int32_t V,
+                      float* row_loss, float* mean_loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

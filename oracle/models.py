@@ -232,7 +232,8 @@ def salmonn_window_count(T: int = 1500, second_per_window: float = 0.333333, sec
 
 
 def salmonn_fuse_qformer(sd: SD, speech: Tensor, audio: Optional[Tensor], rnd: Optional[Callable] = None,
-                         second_per_window: float = 0.333333, second_stride: float = 0.333333) -> Tensor:
+                         second_per_window: float = 0.333333, second_stride: float = 0.333333,
+                         qformer_heads: int = 12) -> Tensor:
     """SALMONN._encode_auditory_feature: speech [B,1500,1280] (Whisper out), audio [B,Ta,768] (BEATs out or None)
     -> [B, n_windows, H_llm]."""
     rnd = rnd or _id
@@ -251,20 +252,20 @@ def salmonn_fuse_qformer(sd: SD, speech: Tensor, audio: Optional[Tensor], rnd: O
     ov = F.unfold(tr, kernel_size=(1, kernel), dilation=1, padding=0, stride=(1, stride))
     ov = ov.view(B, -1, kernel, L).permute(0, 3, 2, 1).reshape(-1, kernel, C)
     qt = sd["speech_query_tokens"].float().expand(ov.shape[0], -1, -1)
-    qo = qformer(sd, qt, ov, rnd=rnd)
+    qo = qformer(sd, qt, ov, n_heads=qformer_heads, rnd=rnd)
     out = _lin(qo, sd, "speech_llama_proj", rnd)
     return out.view(B, -1, out.shape[-1]).contiguous()
 
 
 def salmonn_encode_speech(sd: SD, spec: Tensor, wav: Optional[Tensor], wav_lens: Optional[List[int]],
                           whisper_heads: int, use_beats: bool = True, rnd: Optional[Callable] = None,
-                          beats_cfg: Optional[dict] = None) -> Tensor:
+                          beats_cfg: Optional[dict] = None, qformer_heads: int = 12) -> Tensor:
     """SALMONN.encode_speech(spectrogram, raw_wav, audio_padding_mask) -> [B, 88, H_llm]."""
     speech = whisper_encoder(sd, spec, whisper_heads, prefix="speech_encoder.", rnd=rnd)
     audio = None
     if use_beats and wav is not None:
         audio, _ = beats_encoder(sd, wav, wav_lens, prefix="beats.", rnd=rnd, **(beats_cfg or {}))
-    return salmonn_fuse_qformer(sd, speech, audio, rnd=rnd)
+    return salmonn_fuse_qformer(sd, speech, audio, rnd=rnd, qformer_heads=qformer_heads)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -285,7 +286,8 @@ class LlamaOracle:
         self.Hkv = n_kv_heads or n_heads
 
     def embed(self, ids: Tensor) -> Tensor:
-        return self.sd["model.embed_tokens.weight"].float()[ids]
+        # the HIP path keeps the embedding table in bf16 (rnd = bf16_round reproduces that)
+        return self.rnd(self.sd["model.embed_tokens.weight"].float()[ids])
 
     def _rms(self, x: Tensor, name: str) -> Tensor:
         return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.sd[name].float()

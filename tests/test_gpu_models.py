@@ -1,0 +1,211 @@
+"""End-to-end parity of the HIP kernel chains (runtime/engines.py, runtime/salmonn.py) against the CPU
+oracle (oracle/models.py) on identical seeded weights and inputs, at miniature shapes (`-m gpu`).
+
+Two comparisons per stage:
+  * oracle with the bf16 rounding hook (same rounding points as the HIP path)  -> tight tolerance;
+  * oracle in pure fp32 (the reference's CPU behaviour)                         -> bf16-level tolerance.
+Tolerances are relative L2 errors over the whole tensor, stated next to each assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def env():
+    from icl_speech_text_llm_amd.runtime import synth
+    from icl_speech_text_llm_amd.runtime.config import SalmonnCfg
+    from icl_speech_text_llm_amd.runtime.salmonn import SalmonnRuntime
+    cfg = SalmonnCfg.tiny(use_beats=True, lora=True)
+    sd = synth.salmonn_state(cfg, seed=0, jitter=True)
+    rt = SalmonnRuntime(cfg, dict(sd), device=DEV)
+    return cfg, sd, rt
+
+
+def _wavs(lens, L=None, seed=1234):
+    L = L or max(lens)
+    wav = torch.zeros(len(lens), L)
+    for i, n in enumerate(lens):
+        rng = np.random.default_rng(seed + i)
+        wav[i, :n] = torch.from_numpy(np.clip(rng.normal(0, 0.1, n), -1, 1).astype(np.float32))
+    return wav
+
+
+def test_whisper_encoder(env):
+    from oracle import audio_frontend as af, models as om
+    cfg, sd, rt = env
+    lens = [48000, 480000]
+    wav = _wavs(lens)
+    spec = torch.stack([torch.from_numpy(af.whisper_logmel(wav[i, :n].numpy())) for i, n in enumerate(lens)])
+    xt = rt.logmel.from_spectrogram(rt.ws, spec.to(DEV))
+    got = rt.whisper.forward(rt.ws, xt).view(2, 1500, -1)
+    ref_b = om.whisper_encoder(sd, spec, cfg.whisper.n_heads, "speech_encoder.", rnd=om.bf16_round)
+    ref_f = om.whisper_encoder(sd, spec, cfg.whisper.n_heads, "speech_encoder.")
+    eb, ef = _rel(got, ref_b), _rel(got, ref_f)
+    print(f"whisper: rel err vs bf16-rounding oracle {eb:.2e}, vs fp32 oracle {ef:.2e}")
+    assert eb < 4e-3 and ef < 2e-2
+
+
+def test_beats_encoder(env):
+    from oracle import models as om
+    cfg, sd, rt = env
+    lens = [16000 * 3 + 123, 16000 * 5]
+    L = max(lens)
+    wav = _wavs(lens, L)
+    # (a) batch-1 semantics: every audio at its own length
+    got, cu, T = rt.beats.forward(rt.ws, wav.to(DEV), lens, lens)
+    got = got.clone()
+    for i, n in enumerate(lens):
+        ref_b, pm = om.beats_encoder(sd, wav[i:i + 1, :n], [n], prefix="beats.", n_heads=cfg.beats.n_heads, rnd=om.bf16_round)
+        ref_f, _ = om.beats_encoder(sd, wav[i:i + 1, :n], [n], prefix="beats.", n_heads=cfg.beats.n_heads)
+        assert ref_b.shape[1] == T[i] and not pm.any()
+        eb, ef = _rel(got[cu[i]:cu[i + 1]], ref_b[0]), _rel(got[cu[i]:cu[i + 1]], ref_f[0])
+        print(f"beats[{i}] T={T[i]}: rel err vs bf16-rounding oracle {eb:.2e}, vs fp32 oracle {ef:.2e}")
+        assert eb < 6e-3 and ef < 3e-2
+    # (b) padded-batch semantics (speech exemplars): both audios run at L with a key padding mask
+    got, cu, T = rt.beats.forward(rt.ws, wav.to(DEV), [L, L], lens)
+    ref_b, pm = om.beats_encoder(sd, wav, lens, prefix="beats.", n_heads=cfg.beats.n_heads, rnd=om.bf16_round)
+    assert pm[0].any()
+    for i in range(2):
+        valid = ~pm[i]
+        eb = _rel(got[cu[i]:cu[i + 1]][valid], ref_b[i][valid])
+        print(f"beats padded[{i}]: valid rows {int(valid.sum())}/{T[i]} rel err {eb:.2e}")
+        assert eb < 6e-3
+
+
+def test_encode_speech_full(env):
+    from oracle import audio_frontend as af, models as om
+    cfg, sd, rt = env
+    lens = [16000 * 4, 16000 * 6 + 77]
+    wav = _wavs(lens)
+    got = rt.encode_speech(wav, lens).clone()
+    assert got.shape == (2, 88, cfg.llama.hidden)
+    for i, n in enumerate(lens):
+        spec = torch.from_numpy(af.whisper_logmel(wav[i, :n].numpy()))[None]
+        ref_b = om.salmonn_encode_speech(sd, spec, wav[i:i + 1, :n], [n], cfg.whisper.n_heads, rnd=om.bf16_round,
+                                         beats_cfg=dict(n_heads=cfg.beats.n_heads), qformer_heads=cfg.qformer.n_heads)
+        ref_f = om.salmonn_encode_speech(sd, spec, wav[i:i + 1, :n], [n], cfg.whisper.n_heads,
+                                         beats_cfg=dict(n_heads=cfg.beats.n_heads), qformer_heads=cfg.qformer.n_heads)
+        eb, ef = _rel(got[i], ref_b[0]), _rel(got[i], ref_f[0])
+        print(f"encode_speech[{i}]: rel err vs bf16-rounding oracle {eb:.2e}, vs fp32 oracle {ef:.2e}")
+        assert eb < 8e-3 and ef < 3e-2
+    # spectrogram supplied by the caller (the reference's batch dict) must give the same result as in-path K1
+    spec_in = rt.log_mel(wav, lens).clone()
+    got2 = rt.encode_speech(wav, lens, spectrogram=spec_in)
+    assert _rel(got2, got) < 1e-6
+
+
+def _llama_oracle(cfg, sd, rnd=None):
+    from oracle import models as om
+    lsd = {k[len("llama_model."):]: v for k, v in sd.items() if k.startswith("llama_model.")}
+    return om.LlamaOracle(lsd, cfg.llama.n_heads, cfg.llama.rms_eps, cfg.llama.rope_theta, cfg.llama.lora_scale, rnd=rnd)
+
+
+def _prompts(cfg, lens, n_speech=0, seed=99):
+    from icl_speech_text_llm_amd.runtime.salmonn import speech_segment
+    out = []
+    for i, n in enumerate(lens):
+        rng = np.random.default_rng(seed + i)
+        ids = rng.integers(3, cfg.llama.vocab - 1, n).tolist()
+        if n_speech:
+            k = n // 2
+            out.append([ids[:k], speech_segment(i * n_speech, n_speech), ids[k:]])
+        else:
+            out.append([ids])
+    return out
+
+
+def test_llama_forward_logits_and_loss(env):
+    from oracle import models as om
+    cfg, sd, rt = env
+    lens = [37, 150, 64]
+    prompts = _prompts(cfg, lens, n_speech=5)
+    speech = torch.randn(3, 5, cfg.llama.hidden) * 0.05
+    logits, got_lens = rt.forward_logits(prompts, speech.to(DEV))
+    logits = logits.clone()
+    assert got_lens == [n + 5 for n in lens]
+    ob, of = _llama_oracle(cfg, sd, om.bf16_round), _llama_oracle(cfg, sd)
+    off = 0
+    for i, segs in enumerate(prompts):
+        emb = torch.cat([ob.embed(torch.tensor(segs[0])), speech[i], ob.embed(torch.tensor(segs[2]))])[None]
+        emb = emb.to(torch.bfloat16).float() if False else emb
+        S = emb.shape[1]
+        labels = torch.full((1, S), -100, dtype=torch.long)
+        labels[0, -6:] = torch.tensor(segs[2][-6:])
+        lb, loss_b = ob.forward(emb, labels)
+        lf, _ = of.forward(emb, labels)
+        g = logits[off:off + S]
+        eb, ef = _rel(g, lb[0]), _rel(g, lf[0])
+        print(f"llama logits[{i}] S={S}: rel err vs bf16-rounding oracle {eb:.2e}, vs fp32 oracle {ef:.2e}; "
+              f"max abs {float((g.cpu() - lb[0]).abs().max()):.2e} (|logit| max {float(lb.abs().max()):.2f})")
+        assert eb < 5e-3 and ef < 2e-2
+        shifted = torch.full((S,), -100, dtype=torch.int32)
+        shifted[:-1] = labels[0, 1:].to(torch.int32)
+        loss = rt.cross_entropy(g, shifted).cpu()
+        assert abs(float(loss) - float(loss_b)) < 2e-3 * max(1.0, abs(float(loss_b)))
+        off += S
+
+
+def test_llama_generate_matches_oracle(env):
+    from oracle import models as om
+    cfg, sd, rt = env
+    lens = [33, 90, 61, 12]
+    prompts = _prompts(cfg, lens, seed=7)
+    res = rt.generate(prompts, None, max_new_tokens=10, want_first_logits=True)
+    ob = _llama_oracle(cfg, sd, om.bf16_round)
+    for i, segs in enumerate(prompts):
+        emb = ob.embed(torch.tensor(segs[0]))[None]
+        ids, first = ob.generate_greedy(emb, 10, cfg.llama.eos_id, cfg.llama.pad_id, return_first_logits=True)
+        err = float((res.first_logits[i].cpu() - first[0]).abs().max())
+        top2 = first[0].topk(2).values
+        margin = float(top2[0] - top2[1])
+        got = res.tokens[i].tolist()
+        print(f"generate[{i}]: first-logit max abs err {err:.2e}, oracle top-1 margin {margin:.2e}, ids {got}")
+        assert err < 5e-3 * max(1.0, float(first.abs().max()))
+        exp = ids[0].tolist()
+        # greedy ids must be identical wherever the oracle's own decision is not a numerical coin flip
+        if margin > 20 * err:
+            assert got[0] == exp[0]
+        assert len(got) <= 10
+
+
+def test_generate_eos_and_pad_semantics(env):
+    """EOS at step 0 -> width-1 output; a row finishing early is filled with pad."""
+    from icl_speech_text_llm_amd.runtime import synth
+    from icl_speech_text_llm_amd.runtime.config import SalmonnCfg
+    from icl_speech_text_llm_amd.runtime.salmonn import SalmonnRuntime
+    from oracle import models as om
+    cfg = SalmonnCfg.tiny(use_beats=False, lora=False)
+    sd = synth.salmonn_state(cfg, seed=3, jitter=True, parts=("llama",))
+    # force EOS: make the EOS row of lm_head dominate for every hidden state by aligning it with the final norm gain
+    lm = sd["llama_model.lm_head.weight"]
+    prompts = _prompts(cfg, [20, 31], seed=5)
+    rt = SalmonnRuntime(cfg, dict(sd), device=DEV, parts=("llama",))
+    base = rt.generate(prompts, None, max_new_tokens=6)
+    # pick the token row 0 emits at step 2 and declare it to be EOS: row 0 must then stop there and be pad-filled
+    eos = int(base.tokens[0, 2])
+    res = rt.generate(prompts, None, max_new_tokens=6, eos_id=eos, pad_id=cfg.llama.pad_id)
+    row0 = res.tokens[0].tolist()
+    first = row0.index(eos)
+    assert all(t == cfg.llama.pad_id for t in row0[first + 1:])
+    lsd = {k[len("llama_model."):]: v for k, v in sd.items()}
+    ob = om.LlamaOracle(lsd, cfg.llama.n_heads, cfg.llama.rms_eps, rnd=om.bf16_round)
+    embs = [ob.embed(torch.tensor(p[0]))[None] for p in prompts]
+    # oracle semantics on the same ids: width = longest row, pad after EOS
+    exp_w = 0
+    for i, e in enumerate(embs):
+        ids = ob.generate_greedy(e, 6, eos, cfg.llama.pad_id)
+        exp_w = max(exp_w, ids.shape[1])
+    assert res.tokens.shape[1] <= 6 and res.tokens.shape[1] >= first + 1
+    # EOS at step 0 for every row -> width 1
+    eos0 = int(base.tokens[0, 0])
+    res1 = rt.generate(prompts[:1], None, max_new_tokens=6, eos_id=eos0)
+    assert res1.tokens.shape == (1, 1) and int(res1.tokens[0, 0]) == eos0
