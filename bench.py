@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — ICL utterances/s of the MI355X-native hot path (BASELINE.json metric).
+
+One *step* = one pass of the whole hot path over one micro-batch of synthetic utterances:
+K1 log-mel -> Whisper-large-v2 encoder ‖ BEATs -> LN/concat -> window Q-Former -> projector ->
+prompt interleave -> Llama-2-7B prefill -> greedy decode to exactly 10 new tokens (EOS suppressed).
+Workload at N=1: BASELINE.json configs[1] (C2: speech_only, 5 text exemplars, VOXCELEB;
+prompt = 288 text tokens + 88 audio tokens = 376 positions).  Inputs (30 s / 16 kHz
+waveforms and token ids) are resident in HBM before the timed region; weights are seeded random
+N(0, 0.02^2) in bf16 (no checkpoints are reachable offline).
+
+Multi-GPU: one process per GPU (torch.distributed over RCCL), utterances sharded by rank (weak scaling:
+fixed per-GPU micro-batch); the only collective is one all-gather of the generated ids per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel: the
+128x128 bf16 MFMA GEMM, timed live with HIP events on the launch stream) and, at N=1, `cpu_baseline`
+(the fp32 CPU oracle on one utterance of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+S_TEXT, N_AUDIO_TOK, NEW_TOKENS = 288, 88, 10
+SPEECH_AT = 280             # the <SpeechHere> slot sits near the end of the VOXCELEB prompt ("...\nOutput:")
+
+
+def log(msg: str):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """CPU cores this process may actually use: cgroup quota, else scheduler affinity, else cpu_count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, q // int(f2.read())))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-profile", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="miniature model (smoke only; not a valid bench number)")
+    return ap.parse_args()
+
+
+def synth_utterances(first: int, count: int, vocab: int):
+    """SURVEY.md §8d synthetic inputs: audio N(0,0.1^2) clipped, default_rng(1234+i); ids uniform [3,32000), default_rng(99+i)."""
+    wav = np.empty((count, 480000), dtype=np.float32)
+    ids = np.empty((count, S_TEXT), dtype=np.int64)
+    for j in range(count):
+        i = first + j
+        wav[j] = np.clip(np.random.default_rng(1234 + i).normal(0.0, 0.1, 480000), -1.0, 1.0).astype(np.float32)
+        ids[j] = np.random.default_rng(99 + i).integers(3, min(32000, vocab - 1), S_TEXT)
+    return wav, ids
+
+
+def build_prompts(ids: np.ndarray):
+    from icl_speech_text_llm_amd.runtime.salmonn import speech_segment
+    return [[row[:SPEECH_AT].tolist(), speech_segment(b * N_AUDIO_TOK, N_AUDIO_TOK), row[SPEECH_AT:].tolist()]
+            for b, row in enumerate(ids)]
+
+
+def cpu_baseline(cfg, sd_gpu, wav: np.ndarray, ids: np.ndarray, threads: int):
+    """The oracle (fp32, batch 1, greedy 10 tokens) on ONE utterance of the same workload, host cores only."""
+    from oracle import audio_frontend as af, models as om
+    torch.set_num_threads(threads)
+    log(f"cpu_baseline: copying {len(sd_gpu)} tensors to host fp32 ...")
+    sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd_gpu.items()}
+    log(f"cpu_baseline: running the fp32 oracle on 1 utterance with {threads} threads ...")
+    t0 = time.perf_counter()
+    spec = torch.from_numpy(af.whisper_logmel(wav))[None]
+    emb = om.salmonn_encode_speech(sd, spec, torch.from_numpy(wav)[None], [wav.shape[0]], cfg.whisper.n_heads,
+                                   use_beats=cfg.beats is not None,
+                                   beats_cfg=dict(n_heads=cfg.beats.n_heads, num_buckets=cfg.beats.num_buckets,
+                                                  max_distance=cfg.beats.max_distance) if cfg.beats else None,
+                                   qformer_heads=cfg.qformer.n_heads)
+    lsd = {k[len("llama_model."):]: v for k, v in sd.items() if k.startswith("llama_model.")}
+    llm = om.LlamaOracle(lsd, cfg.llama.n_heads, cfg.llama.rms_eps, cfg.llama.rope_theta, cfg.llama.lora_scale)
+    x = torch.cat([llm.embed(torch.from_numpy(ids[:SPEECH_AT])), emb[0], llm.embed(torch.from_numpy(ids[SPEECH_AT:]))])[None]
+    log(f"cpu_baseline: speech encoders done at {time.perf_counter() - t0:.1f} s; Llama prefill + decode ...")
+    out = llm.generate_greedy(x, NEW_TOKENS, eos_id=-1, pad_id=cfg.llama.pad_id)
+    dt = time.perf_counter() - t0
+    return dt, out[0].tolist()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from icl_speech_text_llm_amd.runtime import binding as B, synth
+    from icl_speech_text_llm_amd.runtime.config import SalmonnCfg
+    from icl_speech_text_llm_amd.runtime.salmonn import SalmonnRuntime
+
+    cfg = SalmonnCfg.tiny() if args.tiny else SalmonnCfg.llama2_7b()
+    log(f"building {'tiny' if args.tiny else 'SALMONN-7B'} synthetic weights on {dev} ...")
+    t_build = time.perf_counter()
+    sd = synth.salmonn_state(cfg, seed=0, device=dev, dtype=torch.bfloat16)   # identical replica on every rank
+    rt = SalmonnRuntime(cfg, dict(sd), device=dev)
+    want_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline)
+    if not want_cpu:
+        del sd
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    log(f"model packed in {t_build:.1f} s ({torch.cuda.memory_allocated(dev) / 2**30:.1f} GiB allocated)")
+
+    # ---- inputs, resident in HBM before the timed region ----------------------------------------
+    Bm, total_steps = args.batch, args.warmup + args.steps
+    wavs, prompts = [], []
+    lens = [480000] * Bm
+    for s in range(total_steps):
+        first = (s * world + rank) * Bm           # utterance i belongs to rank (i // Bm) % world of step i // (Bm*world)
+        w, ids = synth_utterances(first, Bm, cfg.llama.vocab)
+        wavs.append(torch.from_numpy(w).to(dev))
+        prompts.append(build_prompts(ids))
+        if s == 0:
+            w0, ids0 = w[0].copy(), ids[0].copy()
+    gathered = torch.empty(world * Bm, NEW_TOKENS, dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step(s):
+        speech = rt.encode_speech(wavs[s], lens)
+        res = rt.generate(prompts[s], speech, max_new_tokens=NEW_TOKENS, suppress_eos=True)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, rt.ws.get("gen_tokens", (Bm, NEW_TOKENS), torch.int32))
+        return res.tokens
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"inputs resident ({total_steps} x {Bm} utterances); warmup ...")
+    first_tokens = None
+    for s in range(args.warmup):
+        toks = step(s)
+        torch.cuda.synchronize()
+        log(f"warmup step {s} done")
+        if s == 0:
+            first_tokens = toks[0].tolist()
+    profile = None if args.no_gemm_profile else []
+    barrier()
+    B.GEMM_PROFILE = profile
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        toks = step(s)
+        if first_tokens is None and s == 0:
+            first_tokens = toks[0].tolist()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    B.GEMM_PROFILE = None
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (128x128 MFMA GEMM), from live HIP-event timings -------
+    roof = None
+    if profile:
+        big = [(f, e0.elapsed_time(e1) * 1e-3) for (tile, sk, f, e0, e1) in profile if tile == 1]
+        allg = [(f, e0.elapsed_time(e1) * 1e-3) for (tile, sk, f, e0, e1) in profile]
+        if big:
+            fl, tt = sum(f for f, _ in big), sum(t for _, t in big)
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<2,2,4,4> (128x128x64 tile)",
+                    "achieved": round(fl / tt / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": len(big), "avg_launch_us": round(tt / len(big) * 1e6, 2),
+                    "avg_launch_gflop": round(fl / len(big) / 1e9, 3),
+                    "share_of_step_time": round(tt / elapsed, 3),
+                    "all_gemm_share_of_step_time": round(sum(t for _, t in allg) / elapsed, 3)}
+
+    if rank == 0:
+        n_utt = Bm * args.steps * world
+        out = {
+            "metric": "ICL utterances/sec (whole node), SALMONN+Llama2-7B 5-shot VOXCELEB",
+            "value": round(n_utt / elapsed, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C2: SALMONN (Whisper-large-v2 + BEATs + Llama2-7B) speech_only 5-shot VOXCELEB"
+                                   if not args.tiny else "TINY smoke model (not a benchmark)",
+                       "utterances_per_step_per_gpu": Bm, "prompt_positions": S_TEXT + N_AUDIO_TOK,
+                       "audio_seconds": 30, "new_tokens": NEW_TOKENS, "parallelism": f"dp{world}",
+                       "weights": "seeded N(0,0.02^2) bf16, LoRA r=8 un-merged"},
+            "roofline": roof,
+            "build_s": round(t_build, 1), "first_utterance_tokens": first_tokens,
+        }
+        if want_cpu:
+            threads = host_cores()
+            dt, cpu_tokens = cpu_baseline(cfg, sd, w0, ids0, threads)
+            out["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "utterances/s", "cores": threads, "kind": "port",
+                                   "sample": f"1 utterance of the same C2 workload (30 s audio, 376 positions, 10 greedy "
+                                             f"tokens), fp32 torch-CPU oracle, {dt:.1f} s",
+                                   "tokens": cpu_tokens, "tokens_match_gpu": cpu_tokens == first_tokens}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

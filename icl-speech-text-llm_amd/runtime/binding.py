@@ -21,6 +21,11 @@ EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 1, 2, 4, 8
 ABI_VERSION = 1
 
 
+# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
+# entries are (tile, split_k, algorithmic_flops, start_event, end_event)
+GEMM_PROFILE = None
+
+
 class IclError(RuntimeError):
     """Raised when a libicl_hip entry point returns a negative code."""
 
@@ -175,9 +180,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, resi
     g.out_dtype = _dt(out)
     g.res_dtype = _dt(residual) if residual is not None else ICL_F32
     g.split_k = split_k
+    if tile == 0:  # same rule as the library's auto choice, made here so a profiler hook knows the kernel
+        t128 = ((g.M + 127) // 128) * ((N + 127) // 128) * batch
+        tile = 2 if (g.M <= 64 or t128 < 256) else 1
     g.tile = tile
     if split_k > 1 and workspace is not None:
         assert workspace.dtype == torch.float32 and workspace.numel() >= split_k * g.M * N
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(lib.icl_gemm_bf16(ctypes.byref(g), _stream()), "icl_gemm_bf16")
+        e1.record()
+        GEMM_PROFILE.append((tile, split_k, 2.0 * g.M * N * g.K * batch, e0, e1))
+        return out
     _check(lib.icl_gemm_bf16(ctypes.byref(g), _stream()), "icl_gemm_bf16")
     return out
 
