@@ -1,0 +1,123 @@
+"""Input side of the hot path: prompt formatting, per-item processing and batch collation.
+
+Mirrors the reference's ``SalmonProcessor`` (data/model_processors.py:476-874) for the classification
+tasks: ``format_prompt`` reproduces ``_format_default_prompt`` (:742-776) character for character (the
+prompt text fixes the token count S), ``process_inputs`` / ``collate_batch`` emit the batch dict of
+SURVEY.md §8(a-0) (:616-681, :786-874).
+
+MI355X-first difference: the log-mel (K1) moved onto the GPU, so by default the processor ships
+``raw_wav`` (as float32 — the reference's ``torch.tensor(audio)`` keeps numpy float64) and NO
+``spectrogram``; DataLoader workers never touch HIP.  Pass ``compute_spectrogram=True`` together with a
+WhisperFeatureExtractor-compatible ``feature_extractor`` to reproduce the reference's CPU behaviour.
+SQA (two-audio) items are out of scope for this round.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pad_sequence
+
+from .task_configs import DatasetType
+
+
+class SalmonProcessor:
+    def __init__(self, tokenizer, max_length: int = 128, feature_extractor=None, compute_spectrogram: bool = False):
+        self.tokenizer = tokenizer
+        self.max_length = max_length
+        self.processor = feature_extractor
+        self.compute_spectrogram = compute_spectrogram and feature_extractor is not None
+        self.batch_counter = 0
+
+    # ---- prompt text -----------------------------------------------------------------------------
+    def format_prompt(self, template: str, text: str, examples: Optional[List[Dict]] = None,
+                      input_mode: str = "speech_and_text", fewshot_mode: str = "text",
+                      dataset_type: Optional[DatasetType] = None, **kwargs) -> str:
+        examples_text = ""
+        if examples:
+            if fewshot_mode == "speech":
+                blocks = [f"<Speech><Example{i}></Speech>\nOutput: {ex.get('label', '')}" for i, ex in enumerate(examples)]
+            else:
+                blocks = [f"Text: {ex.get('text', '')}\nOutput: {ex.get('label', '')}" for ex in examples]
+            examples_text = "\nHere are few examples to learn from:\n" + "\n\n".join(blocks) + "\n\n"
+        if input_mode == "speech_and_text":
+            input_section = f"<Speech><SpeechHere></Speech>\nTranscript: {text}"
+        elif input_mode == "text_only":
+            input_section = f"Text: {text}"
+        else:
+            input_section = "<Speech><SpeechHere></Speech>"
+        return f"{template}\n{examples_text}Now analyze this input:\n{input_section}\nOutput:"
+
+    # ---- one item ----------------------------------------------------------------------------------
+    def _audio(self, audio) -> Dict[str, Any]:
+        wav = torch.as_tensor(np.asarray(audio), dtype=torch.float32).reshape(-1)
+        out = {"raw_wav": wav, "wav_length": int(wav.numel()), "spectrogram": None}
+        if self.compute_spectrogram:
+            out["spectrogram"] = self.processor(np.asarray(audio), sampling_rate=16000, return_tensors="pt").input_features.squeeze(0)
+        return out
+
+    def process_inputs(self, data: Dict[str, Any], is_training: bool = False) -> Dict[str, Any]:
+        if data.get("dataset_type") is not None and str(getattr(data["dataset_type"], "value", data["dataset_type"])) == "sqa":
+            raise NotImplementedError("SQA (question+document audio) items are not supported by the MI355X path yet")
+        input_mode = data.get("input_mode", "speech_only")
+        tok = self.tokenizer(data.get("prompt", ""), padding="max_length", truncation=True, max_length=self.max_length,
+                             return_tensors="pt")
+        main = {"raw_wav": None, "wav_length": 0, "spectrogram": None}
+        if data.get("audio") is not None and "speech" in input_mode:
+            main = self._audio(data["audio"])
+        examples = [self._audio(a) for a in (data.get("examples_audio") or [])]
+        self.batch_counter += 1
+        return {"input_ids": tok.input_ids, "attention_mask": tok.attention_mask, "spectrogram": main["spectrogram"],
+                "raw_wav": main["raw_wav"], "wav_length": main["wav_length"], "examples_speech": examples,
+                "num_examples": len(examples), "completion": data.get("completion", "")}
+
+    # ---- batch -------------------------------------------------------------------------------------
+    def collate_batch(self, items: List[Dict[str, Any]]) -> Dict[str, Any]:
+        batch: Dict[str, Any] = {
+            "input_ids": torch.stack([it["input_ids"] for it in items]),
+            "attention_mask": torch.stack([it["attention_mask"] for it in items]),
+        }
+        if all(it.get("raw_wav") is not None for it in items):
+            lens = torch.tensor([it["wav_length"] for it in items])
+            wavs = pad_sequence([it["raw_wav"] for it in items], batch_first=True, padding_value=0.0)
+            batch["wav_lengths"] = lens
+            batch["raw_wav"] = wavs
+            batch["padding_mask"] = torch.arange(wavs.size(1)).unsqueeze(0) >= lens.unsqueeze(1)
+            if all(it.get("spectrogram") is not None for it in items):
+                batch["spectrogram"] = torch.stack([it["spectrogram"] for it in items])
+        max_examples = max(it["num_examples"] for it in items)
+        if max_examples > 0 and any(it.get("examples_speech") for it in items):
+            max_len = max(ex["wav_length"] for it in items for ex in it["examples_speech"][:it["num_examples"]])
+            have_spec = all(ex["spectrogram"] is not None for it in items for ex in it["examples_speech"])
+            ex_wavs, ex_masks, ex_lens, ex_specs = [], [], [], []
+            for it in items:
+                w = torch.zeros(max_examples, max_len)
+                m = torch.ones(max_examples, max_len, dtype=torch.bool)
+                l = torch.zeros(max_examples, dtype=torch.long)
+                s = torch.zeros(max_examples, 80, 3000)
+                for e, ex in enumerate(it["examples_speech"][:it["num_examples"]]):
+                    n = ex["wav_length"]
+                    w[e, :n] = ex["raw_wav"]
+                    m[e, :n] = False
+                    l[e] = n
+                    if have_spec:
+                        s[e] = ex["spectrogram"]
+                ex_wavs.append(w); ex_masks.append(m); ex_lens.append(l); ex_specs.append(s)
+            batch["example_wavs"] = torch.stack(ex_wavs)
+            batch["example_padding_masks"] = torch.stack(ex_masks)
+            batch["example_wav_lengths"] = torch.stack(ex_lens)
+            if have_spec:
+                batch["example_spectrograms"] = torch.stack(ex_specs)
+        batch["num_examples"] = torch.tensor([it["num_examples"] for it in items])
+        for key in ("prompt", "completion", "text", "dataset_type"):
+            if key in items[0]:
+                batch[key] = [it[key] for it in items]
+        return batch
+
+
+def get_processor(model_type: str, processor=None, tokenizer=None, **kw):
+    """Reference: data/model_processors.get_processor (:1012-1030)."""
+    if model_type == "salmonn":
+        return SalmonProcessor(tokenizer, feature_extractor=processor, **kw)
+    raise ValueError(f"Unsupported model type for the MI355X path: {model_type}")

@@ -1,0 +1,106 @@
+"""Tokenizers for the host side of the path.
+
+The reference takes ``llama_tokenizer`` from the external SALMONN object (models/custom_salmon.py:109),
+i.e. ``LlamaTokenizer.from_pretrained(llama_path, use_fast=False)`` plus a ``[PAD]`` special token
+(pad id 32000 -> vocab 32001, SURVEY.md §7 "quirks").  ``load_llama_tokenizer`` does exactly that when
+``llama_path`` is a local directory; offline (no checkpoint reachable) it falls back to ``ByteTokenizer``,
+a dependency-free byte-level tokenizer that honours the small slice of the HF tokenizer call protocol the
+glue uses (``__call__`` with ``padding`` / ``return_tensors="pt"`` / ``add_special_tokens``,
+``batch_decode``, ``decode``, ``pad_token_id``, ``eos_token_id``, ``vocab_size``).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import List, Sequence, Union
+
+import torch
+
+logger = logging.getLogger(__name__)
+
+
+class Encoding(dict):
+    """dict with attribute access and ``.to(device)`` (what the glue needs of a HF BatchEncoding)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def to(self, device):
+        return Encoding({k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in self.items()})
+
+
+class ByteTokenizer:
+    """ids 0..2 = <unk>/<s>/</s>, 3..258 = bytes 0..255, then free ids up to vocab-2, pad = vocab-1."""
+
+    bos_token_id, eos_token_id, unk_token_id = 1, 2, 0
+    padding_side = "right"
+
+    def __init__(self, vocab_size: int = 32001):
+        assert vocab_size >= 260
+        self._vocab = vocab_size
+        self.pad_token_id = vocab_size - 1
+
+    @property
+    def vocab_size(self) -> int:  # HF: size without added tokens
+        return self._vocab - 1
+
+    def __len__(self) -> int:
+        return self._vocab
+
+    def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
+        ids = [b + 3 for b in text.encode("utf-8")]
+        return ([self.bos_token_id] + ids) if add_special_tokens else ids
+
+    def __call__(self, text: Union[str, Sequence[str]], padding=False, truncation=False, max_length=None,
+                 return_tensors=None, add_special_tokens=True, return_attention_mask=True, **_):
+        single = isinstance(text, str)
+        rows = [self.encode(t, add_special_tokens) for t in ([text] if single else list(text))]
+        if truncation and max_length:
+            rows = [r[:max_length] for r in rows]
+        width = max_length if padding == "max_length" and max_length else max((len(r) for r in rows), default=0)
+        do_pad = padding in (True, "longest", "max_length")
+        if do_pad or return_tensors == "pt":
+            if not do_pad and len({len(r) for r in rows}) > 1:
+                raise ValueError("cannot tensorise ragged rows without padding")
+            mask = [[1] * len(r) + [0] * (width - len(r)) for r in rows]
+            rows = [r + [self.pad_token_id] * (width - len(r)) for r in rows]
+        else:
+            mask = [[1] * len(r) for r in rows]
+        if return_tensors == "pt":
+            out = {"input_ids": torch.tensor(rows, dtype=torch.long).reshape(len(rows), width),
+                   "attention_mask": torch.tensor(mask, dtype=torch.long).reshape(len(rows), width)}
+        else:
+            out = {"input_ids": rows[0] if single else rows, "attention_mask": mask[0] if single else mask}
+        return Encoding(out)
+
+    def decode(self, ids, skip_special_tokens: bool = False, **_) -> str:
+        if isinstance(ids, torch.Tensor):
+            ids = ids.tolist()
+        buf = bytearray()
+        for t in ids:
+            t = int(t)
+            if 3 <= t < 259:
+                buf.append(t - 3)
+            elif not skip_special_tokens and t < 3:
+                buf.extend(("<unk>", "<s>", "</s>")[t].encode())
+            # ids >= 259 (unused range, pad) carry no text
+        return buf.decode("utf-8", errors="replace")
+
+    def batch_decode(self, batch, skip_special_tokens: bool = False, **kw) -> List[str]:
+        if isinstance(batch, torch.Tensor):
+            batch = batch.tolist()
+        return [self.decode(row, skip_special_tokens=skip_special_tokens) for row in batch]
+
+
+def load_llama_tokenizer(llama_path: str, vocab_size: int = 32001):
+    if llama_path and os.path.isdir(llama_path):
+        from transformers import AutoTokenizer
+        tok = AutoTokenizer.from_pretrained(llama_path, use_fast=False)
+        tok.add_special_tokens({"pad_token": "[PAD]"})
+        tok.padding_side = "right"
+        return tok
+    logger.warning("llama_path %r is not a local directory: using the byte-level fallback tokenizer", llama_path)
+    return ByteTokenizer(vocab_size)

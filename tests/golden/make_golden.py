@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ (run in the build container only; needs /root/reference and the
+installed `transformers`).  Nothing here ships to the GPU box except the small .npz/.json outputs.
+
+The reference has no tests and no fixtures of its own, and the arithmetic of its hot path lives in
+third-party packages, so the oracle is pinned by vectors minted from
+  (a) the installed transformers modules the reference calls (WhisperFeatureExtractor, WhisperEncoder,
+      LlamaForCausalLM.forward/generate) and — as the architectural stand-in for SALMONN's Q-Former — Blip2QFormerModel,
+      with seeded random weights at miniature dims;
+  (b) the reference's OWN in-tree code, imported from /root/reference: CustomSALMONN.custom_prompt_wrap / forward /
+      generate_output (models/custom_salmon.py) with the absent external `SALMONN.models.salmonn_org` package
+      replaced by a minimal in-memory module (a tiny HF Llama + a byte tokenizer + a deterministic encode_speech),
+      SalmonProcessor._format_default_prompt (data/model_processors.py) and clean_prediction (utils/evaluation_utils.py).
+Usage:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def g1_logmel():
+    from transformers import WhisperFeatureExtractor
+    fe = WhisperFeatureExtractor()
+    out = {"mel_filters_T": fe.mel_filters.astype(np.float64)[::4]}
+    for tag, L, seed in (("0p5s", 8000, 1234), ("7p3s", 116800, 1235), ("30s", 480000, 1236)):
+        wav = np.clip(np.random.default_rng(seed).normal(0, 0.1, L), -1, 1).astype(np.float32)
+        spec = fe(wav, sampling_rate=16000, return_tensors="np")["input_features"][0]
+        out[f"spec_{tag}"] = spec[:, ::12].astype(np.float32)      # every 12th frame keeps the file small
+        out[f"len_{tag}"], out[f"seed_{tag}"] = L, seed
+    save("logmel.npz", **out)
+
+
+def g2_whisper():
+    from transformers import WhisperConfig
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder
+    torch.manual_seed(0)
+    cfg = WhisperConfig(d_model=32, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=64, num_mel_bins=80,
+                        max_source_positions=1500)
+    enc = WhisperEncoder(cfg).eval()
+    with torch.no_grad():
+        for p in enc.parameters():
+            if p.requires_grad:
+                p.copy_(torch.randn_like(p) * (0.15 if p.dim() > 1 else 0.3) + (1.0 if "layer_norm.weight" in "" else 0.0))
+        c, t = torch.arange(80.0)[:, None], torch.arange(3000.0)[None, :]
+        spec = (0.5 * torch.sin(0.01 * (c + 1.0) * t + c))[None]      # closed form: nothing to store
+        out = enc(spec).last_hidden_state
+    sd = {k: v for k, v in enc.state_dict().items() if k != "embed_positions.weight"}   # sinusoids are regenerated
+    save("whisper_tiny.npz", out=out[0, ::25], **{"w:" + k: v for k, v in sd.items()})
+
+
+def g3_qformer():
+    from transformers import Blip2QFormerConfig, Blip2QFormerModel
+    torch.manual_seed(1)
+    cfg = Blip2QFormerConfig(hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                             encoder_hidden_size=48, cross_attention_frequency=1, hidden_dropout_prob=0.0,
+                             attention_probs_dropout_prob=0.0)
+    m = Blip2QFormerModel(cfg).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * (0.2 if p.dim() > 1 else 0.3) + (1.0 if p.dim() == 1 and p.shape[0] == 32 and False else 0.0))
+        query = torch.randn(5, 1, 32)
+        enc = torch.randn(5, 17, 48)
+        out = m(query_embeds=query, encoder_hidden_states=enc, encoder_attention_mask=torch.ones(5, 17, dtype=torch.long)).last_hidden_state
+    # HF Blip2 names -> SALMONN Qformer.py (BERT) names
+    ren = {}
+    for k, v in m.state_dict().items():
+        k2 = k.replace("layernorm.", "embeddings.LayerNorm.").replace(".attention.attention.", ".attention.self.")
+        k2 = k2.replace(".crossattention.attention.", ".crossattention.self.")
+        if k2.startswith("encoder.") or k2.startswith("embeddings."):
+            ren["speech_Qformer.bert." + k2] = v
+    save("qformer_tiny.npz", query=query, enc=enc, out=out, **{"w:" + k: v for k, v in ren.items()})
+
+
+def _tiny_llama(seed=2, vocab=260):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(seed)
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                      num_key_value_heads=2, vocab_size=vocab, rms_norm_eps=1e-5, max_position_embeddings=2048,
+                      pad_token_id=vocab - 1, bos_token_id=1, eos_token_id=2, tie_word_embeddings=False)
+    m = LlamaForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn_like(p) * 0.3 if p.dim() > 1 else 1.0 + 0.1 * torch.randn_like(p))
+    return m
+
+
+def g4_llama():
+    m = _tiny_llama()
+    torch.manual_seed(3)
+    emb = torch.randn(2, 23, 64) * 0.5
+    with torch.no_grad():
+        logits = m(inputs_embeds=emb).logits
+        labels = torch.full((2, 23), -100)
+        labels[:, -5:] = torch.randint(3, 250, (2, 5))
+        loss = m(inputs_embeds=emb, labels=labels).loss
+        free = m.generate(inputs_embeds=emb, attention_mask=torch.ones(2, 23, dtype=torch.long), max_new_tokens=10,
+                          do_sample=False, num_beams=1, min_length=1, pad_token_id=259, eos_token_id=None)
+        # declare the token row 0 emits at step 3 to be EOS: row 0 stops there and is pad-filled, row 1 continues
+        eos_mid = int(free[0, 3])
+        mid = m.generate(inputs_embeds=emb, attention_mask=torch.ones(2, 23, dtype=torch.long), max_new_tokens=10,
+                         do_sample=False, num_beams=1, min_length=1, pad_token_id=259, eos_token_id=eos_mid)
+        eos0 = int(free[0, 0])
+        first = m.generate(inputs_embeds=emb[:1], attention_mask=torch.ones(1, 23, dtype=torch.long), max_new_tokens=10,
+                           do_sample=False, num_beams=1, min_length=1, pad_token_id=259, eos_token_id=eos0)
+    save("llama_tiny.npz", emb=emb, logits=logits, labels=labels, loss=loss, gen_free=free, eos_mid=eos_mid, gen_mid=mid,
+         eos0=eos0, gen_eos0=first, **{"w:" + k: v for k, v in m.state_dict().items()})
+
+
+def g5_reference_glue():
+    """Runs the reference's CustomSALMONN (unmodified, imported from /root/reference) on a stub SALMONN."""
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    llama = _tiny_llama(seed=4)
+    tok = ByteTokenizer(260)
+    H = 64
+    torch.manual_seed(5)
+    proj = torch.randn(34, H) * 0.3
+
+    class StubSALMONN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.llama_model = llama
+            self.llama_tokenizer = tok
+
+        @classmethod
+        def from_config(cls, cfg):
+            return cls()
+
+        def encode_speech(self, spectrogram=None, raw_wav=None, audio_padding_mask=None):
+            B = spectrogram.shape[0]
+            feat = spectrogram.float().mean(dim=1)[:, :88 * 34].reshape(B, 88, 34)
+            emb = torch.tanh(feat @ proj)
+            return emb, torch.ones(B, 88, dtype=torch.long)
+
+    for name in ("SALMONN", "SALMONN.models", "SALMONN.models.salmonn_org"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["SALMONN.models.salmonn_org"].SALMONN = StubSALMONN
+    sys.path.insert(0, REF)
+    from models.custom_salmon import CustomSALMONN as RefSALMONN      # the reference's own class
+    from data.model_processors import SalmonProcessor as RefProcessor
+    from data.master_config import DatasetType as RefDT, get_dataset_config as ref_cfg
+    ref = RefSALMONN(lora=False, device=torch.device("cpu"))
+    rproc = RefProcessor.__new__(RefProcessor)
+    tmpl = ref_cfg(RefDT.VOXCELEB).prompt_template
+    ex = [{"text": f"example sentence number {i} about things", "label": ["positive", "negative", "neutral"][i % 3]} for i in range(5)]
+    torch.manual_seed(6)
+    cases = {}
+    for case, (mode, few, nspeech_ex) in {"text_only": ("text_only", "text", 0), "speech_text_ex": ("speech_only", "text", 0),
+                                           "speech_speech_ex": ("speech_only", "speech", 2)}.items():
+        exs = ex[:nspeech_ex] if few == "speech" else ex
+        prompt = rproc._format_default_prompt(tmpl, "the query sentence to classify", exs, mode, few)
+        samples = {"prompt": [prompt], "completion": ["positive"], "num_examples": torch.tensor([len(exs) if few == "speech" else 0])}
+        if mode != "text_only":
+            samples["spectrogram"] = torch.randn(1, 80, 3000) * 0.5
+            samples["raw_wav"] = torch.zeros(1, 16000)
+            samples["padding_mask"] = torch.zeros(1, 16000, dtype=torch.bool)
+        if few == "speech":
+            samples["example_spectrograms"] = torch.randn(1, nspeech_ex, 80, 3000) * 0.5
+            samples["example_wavs"] = torch.zeros(1, nspeech_ex, 16000)
+            samples["example_padding_masks"] = torch.zeros(1, nspeech_ex, 16000, dtype=torch.bool)
+        with torch.no_grad():
+            ref.batch_counter = 1   # skip the first-batch debug logging
+            sp, sa, ee, ea = ref.get_speech_embeddings(dict(samples))
+            wrapped, watts = ref.custom_prompt_wrap(sp, sa, samples["prompt"], samples["num_examples"], ee, ea)
+            fwd = ref.forward(dict(samples))
+            gen = ref.generate_output(dict(samples))
+            gen_ids = ref.llama_model.generate(inputs_embeds=wrapped, attention_mask=watts, max_new_tokens=10, num_beams=1,
+                                               do_sample=False, min_length=1, pad_token_id=tok.pad_token_id,
+                                               eos_token_id=tok.eos_token_id)
+        arrs = dict(wrapped=wrapped[0], logits_tail=fwd["logits"][0, -12:], labels=fwd["labels"][0], loss=fwd["loss"],
+                    gen_ids=gen_ids[0])
+        if sp is not None:
+            arrs["speech"] = sp[0]
+        if ee is not None:
+            arrs["examples"] = torch.stack(ee[0])
+        cases[case] = {"prompt": prompt, "completion": "positive", "generated_text": gen[0],
+                       "num_examples": int(samples["num_examples"][0]), "S": int(wrapped.shape[1])}
+        save(f"glue_{case}.npz", **arrs)
+    save("glue_llama.npz", **{"w:" + k: v for k, v in llama.state_dict().items()})
+    with open(os.path.join(HERE, "glue_cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    # prompt formatter goldens for all three tasks x modes (SURVEY.md A11 sizes)
+    fmt = {}
+    for dt in (RefDT.VOXCELEB, RefDT.HVB, RefDT.VOXPOPULI):
+        t = ref_cfg(dt).prompt_template
+        for mode in ("speech_only", "text_only", "speech_and_text"):
+            for few in ("text", "speech"):
+                fmt[f"{dt.value}|{mode}|{few}"] = rproc._format_default_prompt(t, "query text", ex[:3], mode, few)
+        fmt[f"{dt.value}|speech_only|zero"] = rproc._format_default_prompt(t, "query text", None, "speech_only", "text")
+    with open(os.path.join(HERE, "format_prompt.json"), "w") as f:
+        json.dump(fmt, f, indent=1)
+
+
+def g8_clean_prediction():
+    sys.path.insert(0, REF)
+    from utils.evaluation_utils import clean_prediction as ref_clean
+    from data.master_config import DatasetType as RefDT
+    raw = ["positive", " Positive.", "The sentiment is negative because", "neutral\nOutput: positive", "Postive", "", "  ",
+           "acknowledge, thanks", "thanks,, statement_close,", ",question_check, foo", "Answer: statement_general (maybe)",
+           "none", "None", "person, place", "place, person, xyz", "law\\n", "org;quant", "when , when", "ORG, NORP,",
+           "negative positive", "it's neutral!", "123", "\\positive", "statement_open,\nthanks"]
+    table = []
+    for dt in (RefDT.VOXCELEB, RefDT.HVB, RefDT.VOXPOPULI):
+        for r in raw:
+            table.append({"dataset_type": dt.value, "raw": r, "cleaned": ref_clean(r, dt)})
+    with open(os.path.join(HERE, "clean_prediction.json"), "w") as f:
+        json.dump(table, f, indent=1)
+    print(f"clean_prediction.json: {len(table)} rows")
+
+
+if __name__ == "__main__":
+    g1_logmel()
+    g2_whisper()
+    g3_qformer()
+    g4_llama()
+    g5_reference_glue()
+    g8_clean_prediction()

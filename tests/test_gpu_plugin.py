@@ -1,0 +1,125 @@
+"""`-m gpu`: the plugin surface (ModelFactory -> CustomSALMONN.forward / generate_output / get_speech_embeddings /
+custom_prompt_wrap) and the CLI, end to end on the HIP path, checked against the oracle on the same weights."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    from icl_speech_text_llm_amd.models.model_factory import ModelFactory
+    m = ModelFactory.create_model("salmonn", device="cuda", arch="tiny", low_resource=True, llama_path="none", lora_alpha=32)
+    return m.eval()
+
+
+def _batch(model, fewshot_mode, input_mode="speech_only", n=2, bs=2, num_examples=2, secs=3.0, vary=True):
+    from icl_speech_text_llm_amd.data.model_processors import get_processor
+    from icl_speech_text_llm_amd.data.synthetic_dataset import SyntheticICLDataset
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType
+    proc = get_processor("salmonn", model.input_processor, model.llama_tokenizer)
+    ds = SyntheticICLDataset(proc, [DatasetType.VOXCELEB], n_items=n, fewshot_mode=fewshot_mode, input_mode=input_mode,
+                             audio_seconds=secs, num_examples=num_examples, vary_length=vary)
+    return next(iter(DataLoader(ds, batch_size=bs, collate_fn=proc.collate_batch)))
+
+
+def _oracle_llama(model, rnd):
+    from oracle import models as om
+    sd = {k[len("llama_model."):]: v.float().cpu() for k, v in model.salmonn.state_dict().items() if k.startswith("llama_model.")}
+    c = model.cfg.llama
+    return om.LlamaOracle(sd, c.n_heads, c.rms_eps, c.rope_theta, c.lora_scale, rnd=rnd)
+
+
+def test_generate_output_text_and_speech_fewshot(model):
+    for few in ("text", "speech"):
+        b = _batch(model, few)
+        out = model.generate_output({k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in b.items()})
+        assert isinstance(out, list) and len(out) == 2 and all(isinstance(s, str) for s in out)
+    assert model.batch_counter == 2
+
+
+def test_get_speech_embeddings_matches_oracle_batch1(model):
+    from oracle import audio_frontend as af, models as om
+    b = _batch(model, "speech", n=1, bs=1, num_examples=2, vary=True)
+    sp, sa, ee, ea = model.get_speech_embeddings(dict(b))
+    assert sp.shape == (1, 88, model.cfg.llama.hidden) and sa.shape == (1, 88) and sa.dtype == torch.long
+    assert len(ee) == 1 and len(ee[0]) == 2 and ee[0][0].shape == (88, model.cfg.llama.hidden)
+    sd = {k: v.float().cpu() for k, v in model.salmonn.state_dict().items()}
+    cfg = model.cfg
+    kw = dict(rnd=om.bf16_round, beats_cfg=dict(n_heads=cfg.beats.n_heads), qformer_heads=cfg.qformer.n_heads)
+    # main audio: batch-1 semantics (padded length == own length)
+    n = int(b["wav_lengths"][0])
+    wav = b["raw_wav"][0, :n]
+    spec = torch.from_numpy(af.whisper_logmel(wav.numpy()))[None]
+    ref = om.salmonn_encode_speech(sd, spec, wav[None], [n], cfg.whisper.n_heads, **kw)
+    rel = float((sp[0].cpu() - ref[0]).norm() / ref[0].norm())
+    assert rel < 8e-3, rel
+    # exemplar audio: the reference encodes the PADDED wav with its padding mask (custom_salmon.py:511-519)
+    for e in range(2):
+        ne = int(b["example_wav_lengths"][0, e])
+        wpad = b["example_wavs"][0, e]
+        spec = torch.from_numpy(af.whisper_logmel(wpad[:ne].numpy()))[None]
+        ref = om.salmonn_encode_speech(sd, spec, wpad[None], [ne], cfg.whisper.n_heads, **kw)
+        rel = float((ee[0][e].cpu() - ref[0]).norm() / ref[0].norm())
+        assert rel < 8e-3, (e, rel)
+
+
+def test_forward_loss_logits_labels(model):
+    from icl_speech_text_llm_amd.models.custom_salmon import build_labels
+    from oracle import models as om
+    b = _batch(model, "text", n=1, bs=1)
+    out = model.forward({k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in b.items()})
+    logits, labels, loss = out["logits"], out["labels"], out["loss"]
+    B, S, V = logits.shape
+    assert B == 1 and V == model.cfg.llama.vocab and labels.shape == (1, S)
+    tgt = model.llama_tokenizer(b["completion"], padding="longest", return_tensors="pt", add_special_tokens=False)
+    T = tgt.input_ids.shape[1]
+    assert torch.equal(labels.cpu(), build_labels(S - T, tgt.input_ids, tgt.attention_mask))      # exact
+    assert int((labels != -100).sum()) == T
+    # oracle on the same wrapped embeddings
+    sp, sa, ee, ea = model.get_speech_embeddings(dict(b))
+    wrapped, atts = model.custom_prompt_wrap(sp, sa, b["prompt"], b["num_examples"], ee, ea)
+    assert wrapped.shape == (1, S - T, model.cfg.llama.hidden) and bool((atts == 1).all())
+    llm = _oracle_llama(model, om.bf16_round)
+    full = torch.cat([wrapped[0].cpu(), llm.embed(tgt.input_ids[0])], 0)[None]
+    ref_logits, ref_loss = llm.forward(full, labels.cpu())
+    rel = float((logits.cpu() - ref_logits).norm() / ref_logits.norm())
+    assert rel < 6e-3, rel
+    assert abs(float(loss) - float(ref_loss)) < 5e-3 * max(1.0, abs(float(ref_loss)))
+
+
+def test_ragged_batch_and_equal_length_wrap(model):
+    b = _batch(model, "text", n=2, bs=2)
+    assert len(set(len(p) for p in b["prompt"])) >= 1
+    out = model.generate_output({k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in b.items()})
+    assert len(out) == 2
+    # custom_prompt_wrap keeps the reference's contract: a dense [B,S,H] stack needs equal lengths
+    sp, sa, ee, ea = model.get_speech_embeddings(dict(b))
+    prompts = [b["prompt"][0], b["prompt"][0] + " x"]
+    with pytest.raises(RuntimeError, match="equal size"):
+        model.custom_prompt_wrap(sp, sa, prompts, b["num_examples"], ee, ea)
+
+
+def test_input_processor_is_whisper_feature_extractor_compatible(model):
+    from oracle import audio_frontend as af
+    wav = np.clip(np.random.default_rng(3).normal(0, 0.1, 20000), -1, 1).astype(np.float32)
+    feats = model.input_processor(wav, sampling_rate=16000, return_tensors="pt").input_features
+    assert feats.shape == (1, 80, 3000)
+    assert float((feats[0] - torch.from_numpy(af.whisper_logmel(wav))).abs().max()) < 1e-4
+
+
+def test_cli_end_to_end(tmp_path):
+    from icl_speech_text_llm_amd.inference.inference import main
+    rc = main(["--peft_model_path", "", "--run_name", "t", "--dataset_type", "voxceleb-hvb", "--arch", "tiny",
+               "--synthetic_items", "3", "--batch_size", "2", "--num_workers", "0", "--results_dir", str(tmp_path),
+               "--device", "cuda"])
+    assert rc == 0
+    files = sorted(os.listdir(tmp_path))
+    assert any(f.endswith("_results.json") for f in files) and any(f.endswith("_metrics.json") for f in files)
+    res = json.load(open(tmp_path / [f for f in files if f.endswith("_results.json")][0]))
+    assert len(res) == 6 and set(res[0]) == {"text", "true_label", "predicted_label (cleaned)", "predicted_label", "dataset_type"}
