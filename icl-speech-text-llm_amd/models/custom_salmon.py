@@ -245,7 +245,8 @@ class CustomSALMONN(BaseModel):
     @staticmethod
     def _lengths(wavs: torch.Tensor, lens, mask) -> List[int]:
         if lens is not None:
-            return [int(x) for x in (lens.tolist() if isinstance(lens, torch.Tensor) else lens)]
+            flat = lens.reshape(-1).tolist() if isinstance(lens, torch.Tensor) else list(lens)
+            return [int(x) for x in flat]
         if mask is not None:
             return (~mask.bool()).sum(dim=-1).reshape(-1).tolist()
         return [wavs.shape[-1]] * int(wavs.numel() // wavs.shape[-1])
