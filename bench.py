@@ -201,18 +201,32 @@ def main():
     # ---- roofline of the dominant kernel (128x128 MFMA GEMM), from live HIP-event timings -------
     roof = None
     if profile:
-        big = [(f, e0.elapsed_time(e1) * 1e-3) for (tile, sk, f, e0, e1) in profile if tile == 1]
-        allg = [(f, e0.elapsed_time(e1) * 1e-3) for (tile, sk, f, e0, e1) in profile]
-        if big:
-            fl, tt = sum(f for f, _ in big), sum(t for _, t in big)
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<2,2,4,4> (128x128x64 tile)",
-                    "achieved": round(fl / tt / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                    "launches": len(big), "avg_launch_us": round(tt / len(big) * 1e6, 2),
-                    "avg_launch_gflop": round(fl / len(big) / 1e9, 3),
-                    "share_of_step_time": round(tt / elapsed, 3),
-                    "all_gemm_share_of_step_time": round(sum(t for _, t in allg) / elapsed, 3)}
+        names = {1: "gemm_bf16_kernel<2,2,4,4> (128x128x64 tile)", 2: "gemm_bf16_kernel<2,2,2,2> (64x64x64 tile)",
+                 3: "gemm256_bf16_kernel (256x256x64 rolling LDS-DMA pipeline)"}
+        per_tile = {}
+        for (tile, sk, f, e0, e1, shape) in profile:
+            fl, tt, n = per_tile.get(tile, (0.0, 0.0, 0))
+            per_tile[tile] = (fl + f, tt + e0.elapsed_time(e1) * 1e-3, n + 1)
+        all_t = sum(v[1] for v in per_tile.values())
+        dom = max(per_tile, key=lambda k: per_tile[k][1])          # dominant kernel = largest share of GPU time
+        fl, tt, n = per_tile[dom]
+        roof = {"bound": "mfma", "kernel": names.get(dom, str(dom)), "achieved": round(fl / tt / 1e12, 1),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "launches": n, "avg_launch_us": round(tt / n * 1e6, 2),
+                "avg_launch_gflop": round(fl / n / 1e9, 3), "share_of_step_time": round(tt / elapsed, 3),
+                "all_gemm_share_of_step_time": round(all_t / elapsed, 3),
+                "other_gemm_kernels": {names.get(k, str(k)): {"achieved_tflops": round(v[0] / v[1] / 1e12, 1),
+                                                             "share_of_step_time": round(v[1] / elapsed, 3), "launches": v[2]}
+                                       for k, v in per_tile.items() if k != dom}}
 
+    if profile and os.environ.get("ICL_BENCH_GEMM_SHAPES"):
+        by_shape = {}
+        for (tile, sk, f, e0, e1, shape) in profile:
+            fl, tt, n = by_shape.get((tile, sk) + shape, (0.0, 0.0, 0))
+            by_shape[(tile, sk) + shape] = (fl + f, tt + e0.elapsed_time(e1) * 1e-3, n + 1)
+        for k, (fl, tt, n) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:40]:
+            log(f"gemm tile={k[0]} sk={k[1]} M={k[2]} N={k[3]} K={k[4]} batch={k[5]}: {n} launches, {tt / n * 1e6:9.1f} us avg, "
+                f"{fl / tt / 1e12:7.1f} TF/s, {100 * tt / elapsed:5.1f}% of step time")
     if rank == 0:
         n_utt = Bm * args.steps * world
         out = {

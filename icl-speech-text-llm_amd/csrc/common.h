@@ -48,8 +48,21 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
   v[1] = (__bf16)hi;
   return __builtin_bit_cast(unsigned int, v);
 }
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): one v_rcp + one v_exp + 6 FMA
+// instead of libm erff's ~40 instructions — the GELU epilogue of a K=1280 GEMM is otherwise VALU-bound.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const float r = 1.0f - poly * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

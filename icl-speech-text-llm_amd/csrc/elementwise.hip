@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void axpby_cast_kernel(const void* in, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// LoRA down-projection into the K-augmentation columns; one block per row, one wave per j.
+// LoRA down-projection into the K-augmentation columns for SMALL M (decode): one block per row, one wave per rank-row j
+// (lanes stride K, 16-B loads).  Large M goes through icl_gemm_bf16 (N = r_total) instead.
 __global__ __launch_bounds__(256) void lora_down_kernel(unsigned short* X, int64_t ldx, int K0,
                                                          const unsigned short* A, int64_t lda,
                                                          int r_total, float scale) {

@@ -33,6 +33,130 @@ constexpr int GROUP_M = 8;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+
+// ---- epilogue helpers shared by all tile shapes ---------------------------------------------------------
+// v[0..3] = C[m][n..n+3] (4 consecutive n owned by one lane).
+__device__ __forceinline__ void epi_store4(const GemmParams& p, int z, int m, int n, f32x4 acc) {
+  if (m >= p.M || n >= p.N) return;
+  const bool has_bias = p.epi & ICL_EPI_BIAS, has_gelu = p.epi & ICL_EPI_GELU, has_res = p.epi & ICL_EPI_RESIDUAL;
+  char* Cb = (char*)p.C;
+  const int64_t cz = (int64_t)z * p.sC, rz = (int64_t)z * p.sR;
+  const bool vec_ok = ((p.ldc & 3) == 0) && (!has_res || (p.ldr & 3) == 0);
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  const bool full = (n + 3 < p.N);
+  if (has_bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (full || n + r < p.N) v[r] += p.bias[n + r];
+  }
+  if (has_gelu) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+  }
+  const int64_t coff = cz + (int64_t)m * p.ldc + n;
+  if (full && vec_ok) {
+    if (has_res) {
+      const int64_t roff = rz + (int64_t)m * p.ldr + n;
+      if (p.res_dtype == ICL_F32) {
+        f32x4 rv = *(const f32x4*)((const char*)p.R + roff * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+      } else {
+        const unsigned short* rp = (const unsigned short*)p.R + roff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf16_bits_to_f32(rp[r]);
+      }
+    }
+    if (p.out_dtype == ICL_BF16) {
+      u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *(u32x2*)(Cb + coff * 2) = pk;
+    } else {
+      *(f32x4*)(Cb + coff * 4) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r >= p.N) continue;
+      float x = v[r];
+      if (has_res) {
+        const int64_t roff = rz + (int64_t)m * p.ldr + n + r;
+        x += (p.res_dtype == ICL_F32) ? ((const float*)p.R)[roff]
+                                      : bf16_bits_to_f32(((const unsigned short*)p.R)[roff]);
+      }
+      if (p.out_dtype == ICL_BF16)
+        ((unsigned short*)Cb)[coff + r] = f32_to_bf16_bits(x);
+      else
+        ((float*)Cb)[coff + r] = x;
+    }
+  }
+}
+// gate block at interleaved rows nt + fq4 + r, up block 16 rows later; output column nt/2 + fq4 + r
+__device__ __forceinline__ void epi_store_swiglu(const GemmParams& p, int z, int m, int nt, int fq4, f32x4 g4, f32x4 u4) {
+  if (m >= p.M || nt >= p.N) return;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float g = g4[r], u = u4[r];
+    if (p.epi & ICL_EPI_BIAS) {
+      g += p.bias[nt + fq4 + r];
+      u += p.bias[nt + 16 + fq4 + r];
+    }
+    v[r] = silu_f(g) * u;
+  }
+  const int64_t off = (int64_t)z * p.sC + (int64_t)m * p.ldc + (nt >> 1) + fq4;
+  if (p.out_dtype == ICL_BF16) {
+    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *(u32x2*)((char*)p.C + off * 2) = pk;
+  } else {
+    *(f32x4*)((char*)p.C + off * 4) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+}
+__device__ __forceinline__ void epi_store_partial(const GemmParams& p, int z, int m, int n, f32x4 acc) {
+  if (m >= p.M || n >= p.N) return;
+  float* dst = p.ws + (int64_t)z * p.M * p.N + (int64_t)m * p.N + n;
+  if (n + 3 < p.N && (p.N & 3) == 0) {
+    *(f32x4*)dst = acc;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < p.N) dst[r] = acc[r];
+  }
+}
+
+// ---- interior-tile fast path: no bounds checks, bias as one 16-B load per n-fragment (prefetched before the K loop),
+// ---- residual fragments loaded as ONE batch (independent loads in flight together), then add + convert + store.
+__device__ __forceinline__ f32x4 load_res4(const GemmParams& p, int64_t roff) {
+  if (p.res_dtype == ICL_F32) return *(const f32x4*)((const char*)p.R + roff * 4);
+  const u32x2 raw = *(const u32x2*)((const char*)p.R + roff * 2);
+  return f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
+               __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ void store_out4(const GemmParams& p, int64_t coff, f32x4 v) {
+  if (p.out_dtype == ICL_BF16) {
+    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *(u32x2*)((char*)p.C + coff * 2) = pk;
+  } else {
+    *(f32x4*)((char*)p.C + coff * 4) = v;
+  }
+}
+__device__ __forceinline__ bool tile_is_interior(const GemmParams& p, int m0, int n0, int BM, int BN) {
+  const bool has_res = p.epi & ICL_EPI_RESIDUAL;
+  return (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldc & 3) == 0) && (!has_res || (p.ldr & 3) == 0) &&
+         (!(p.epi & ICL_EPI_BIAS) || (((uintptr_t)p.bias & 15) == 0));
+}
+__device__ __forceinline__ void block_to_tile(const GemmParams& p, int bid, int& tm, int& tn) {
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);   // bijective XCD remap
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = wgid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = wgid - group * per_group;
+  tm = first_m + in_group % gsize;
+  tn = in_group / gsize;
+}
+
 template <int WAVES_M, int WAVES_N, int MI, int NI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   constexpr int BM = WAVES_M * MI * 16, BN = WAVES_N * NI * 16;
@@ -45,24 +169,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  // ---- block -> output tile: XCD remap (bijective) then grouped order -----------------------
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = blockIdx.x;
-  int wgid;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   int tm, tn;
-  {
-    const int per_group = GROUP_M * p.tiles_n;
-    const int group = wgid / per_group;
-    const int first_m = group * GROUP_M;
-    const int gsize = min(p.tiles_m - first_m, GROUP_M);
-    const int in_group = wgid - group * per_group;
-    tm = first_m + in_group % gsize;
-    tn = in_group / gsize;
-  }
+  block_to_tile(p, blockIdx.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- batch / split-K ------------------------------------------------------------------------
@@ -125,8 +233,38 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Interior tiles fold the epilogue operands into the accumulator INIT: acc = bias (+ residual when no activation
+  // follows), loaded while the first K-tile is in flight, so no dependent global load is left after the K loop.
+  const bool interior = p.split_k == 1 && tile_is_interior(p, m0, n0, BM, BN);
+  const bool fold_res = interior && (p.epi & ICL_EPI_RESIDUAL) && p.res_dtype == ICL_F32 && !(p.epi & (ICL_EPI_GELU | ICL_EPI_SWIGLU));
+
+  // order matters: pure loads first (no use -> no wait), then the LDS-DMA of K-tile 0, then the first use (one wait
+  // that covers everything); a use placed between loads would make hipcc drain vmcnt(0) per load.
+  f32x4 bias_f[NI];
+  if (interior) {
+    if (fold_res && p.res_dtype == ICL_F32) {
+      const int mb = m0 + wm * MI * 16 + fr, nb = n0 + wn * NI * 16 + fq * 4;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = *(const f32x4*)((const float*)p.R + (int64_t)z * p.sR + (int64_t)(mb + i * 16) * p.ldr + nb + j * 16);
+    }
+    if (p.epi & ICL_EPI_BIAS) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bias_f[j] = *(const f32x4*)(p.bias + n0 + wn * NI * 16 + j * 16 + fq * 4);
+    }
+  }
   if (kt0 < kt1) {
+    __builtin_amdgcn_sched_barrier(0);
     stage(0, kt0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (interior && (p.epi & ICL_EPI_BIAS)) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = acc[i][j] + bias_f[j];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
@@ -153,124 +291,60 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------
-  // acc[i][j][r] = C[m][n], m = m0 + wm*MI*16 + i*16 + fr, n = n0 + wn*NI*16 + j*16 + fq*4 + r
-  if (p.split_k > 1) {
-    float* ws = p.ws + (int64_t)z * p.M * p.N;
+  // ---- epilogue: acc[i][j][r] = C[m][n], m = m0 + wm*MI*16 + i*16 + fr, n = n0 + wn*NI*16 + j*16 + fq*4 + r ----
+  if (interior) {
+    const int mb = m0 + wm * MI * 16 + fr, nb = n0 + wn * NI * 16 + fq * 4;
+    if (p.epi & ICL_EPI_SWIGLU) {
+      if constexpr (NI % 2 == 0) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm * MI * 16 + i * 16 + fr;
-      if (m >= p.M) continue;
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; j += 2) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(acc[i][j][r]) * acc[i][j + 1][r];
+            store_out4(p, (int64_t)z * p.sC + (int64_t)(mb + i * 16) * p.ldc + ((n0 + wn * NI * 16 + j * 16) >> 1) + fq * 4, v);
+          }
+      }
+      return;
+    }
+    const bool late_res = (p.epi & ICL_EPI_RESIDUAL) && !fold_res;   // activation, then residual (Whisper conv2 + pos)
+    f32x4 rv[MI][NI];
+    if (late_res) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          rv[i][j] = load_res4(p, (int64_t)z * p.sR + (int64_t)(mb + i * 16) * p.ldr + nb + j * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * NI * 16 + j * 16 + fq * 4;
-        float* dst = ws + (int64_t)m * p.N + n;
-        if (n + 3 < p.N && (p.N & 3) == 0) {
-          *(f32x4*)dst = acc[i][j];
-        } else {
+        f32x4 v = acc[i][j];
+        if (p.epi & ICL_EPI_GELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) dst[r] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
         }
+        if (late_res) v = v + rv[i][j];
+        store_out4(p, (int64_t)z * p.sC + (int64_t)(mb + i * 16) * p.ldc + nb + j * 16, v);
       }
-    }
     return;
   }
-
-  const bool has_bias = p.epi & ICL_EPI_BIAS, has_gelu = p.epi & ICL_EPI_GELU;
-  const bool has_res = p.epi & ICL_EPI_RESIDUAL, swiglu = p.epi & ICL_EPI_SWIGLU;
-  char* Cb = (char*)p.C;
-  const int64_t cz = (int64_t)z * p.sC, rz = (int64_t)z * p.sR;
-
-  if (swiglu) {
-    if constexpr (NI % 2 == 0) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * MI * 16 + i * 16 + fr;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < NI; j += 2) {
-          const int nt = n0 + wn * NI * 16 + j * 16;  // interleaved-row index of the gate block
-          if (nt >= p.N) continue;
-          const int oc = (nt >> 1) + fq * 4;          // output column
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float g = acc[i][j][r], u = acc[i][j + 1][r];
-            if (has_bias) {
-              g += p.bias[nt + fq * 4 + r];
-              u += p.bias[nt + 16 + fq * 4 + r];
-            }
-            v[r] = silu_f(g) * u;
-          }
-          const int64_t off = cz + (int64_t)m * p.ldc + oc;
-          if (p.out_dtype == ICL_BF16) {
-            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            *(u32x2*)(Cb + off * 2) = pk;
-          } else {
-            *(f32x4*)(Cb + off * 4) = f32x4{v[0], v[1], v[2], v[3]};
-          }
-        }
-      }
-    }
-    return;
-  }
-
-  const bool vec_ok = ((p.ldc & 3) == 0) && (!has_res || (p.ldr & 3) == 0);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = m0 + wm * MI * 16 + i * 16 + fr;
-    if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * NI * 16 + j * 16 + fq * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const bool full = (n + 3 < p.N);
-      if (has_bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (full || n + r < p.N) v[r] += p.bias[n + r];
-      }
-      if (has_gelu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      }
-      const int64_t coff = cz + (int64_t)m * p.ldc + n;
-      if (full && vec_ok) {
-        if (has_res) {
-          const int64_t roff = rz + (int64_t)m * p.ldr + n;
-          if (p.res_dtype == ICL_F32) {
-            f32x4 rv = *(const f32x4*)((const char*)p.R + roff * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rv[r];
-          } else {
-            const unsigned short* rp = (const unsigned short*)p.R + roff;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bf16_bits_to_f32(rp[r]);
-          }
-        }
-        if (p.out_dtype == ICL_BF16) {
-          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *(u32x2*)(Cb + coff * 2) = pk;
-        } else {
-          *(f32x4*)(Cb + coff * 4) = f32x4{v[0], v[1], v[2], v[3]};
+      const int nt = n0 + wn * NI * 16 + j * 16;
+      if (p.split_k > 1) {
+        epi_store_partial(p, z, m, nt + fq * 4, acc[i][j]);
+      } else if (p.epi & ICL_EPI_SWIGLU) {
+        if constexpr (NI % 2 == 0) {
+          if ((j & 1) == 0) epi_store_swiglu(p, z, m, nt, fq * 4, acc[i][j], acc[i][j + 1]);
         }
       } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r >= p.N) continue;
-          float x = v[r];
-          if (has_res) {
-            const int64_t roff = rz + (int64_t)m * p.ldr + n + r;
-            x += (p.res_dtype == ICL_F32) ? ((const float*)p.R)[roff]
-                                          : bf16_bits_to_f32(((const unsigned short*)p.R)[roff]);
-          }
-          if (p.out_dtype == ICL_BF16)
-            ((unsigned short*)Cb)[coff + r] = f32_to_bf16_bits(x);
-          else
-            ((float*)Cb)[coff + r] = x;
-        }
+        epi_store4(p, z, m, nt + fq * 4, acc[i][j]);
       }
     }
   }
@@ -317,6 +391,262 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
   }
 }
 
+
+// =================================================================================================================
+// 256x256x64 tile, 8 waves (2 x 4), one block per CU, 128 KiB LDS: a rolling LDS-DMA pipeline (guide §5 "8-phase").
+//
+//  * LDS = 2 buffers (K-tile parity) x 4 regions {A0, A1, B0, B1}; a region = 128 rows x 64 k (16 KiB) = one staging
+//    granule = 2 global_load_lds_dwordx4 per thread.  Wave (wr, wc) owns C rows {wr*64..+63} of BOTH A regions and
+//    C columns {wc*32..+31} of BOTH B regions, so each of the 4 phases of a K-tile (one 64x32 quadrant x K=64 =
+//    16 MFMAs per wave) touches ONE A region and ONE B region for every wave:
+//        P0: read A0,B0 -> q(0,0) | P1: read B1 -> q(0,1) | P2: read A1 -> q(1,1) | P3: (B0 frags kept) -> q(1,0)
+//  * every phase stages exactly one granule, 5-6 phases ahead of its first read and >= 2 phases after the last read of
+//    the region it overwrites:   P0: B1(t+1)  P1: A1(t+1)  P2: A0(t+2)  P3: B0(t+2)
+//    so 4 granules (8 LDS-DMA per thread) stay in flight ACROSS barriers: each phase ends with a counted
+//    `s_waitcnt vmcnt(8)` (never 0 in the loop) + ONE raw s_barrier, then its MFMA cluster under s_setprio(1).
+//  * past the last K-tile the stages re-load the last tile into regions nobody reads any more, which keeps the
+//    vmcnt arithmetic uniform (<= 6 wasted granules per block).
+// =================================================================================================================
+constexpr int T256_REGION = 128 * 128;          // bytes
+constexpr int T256_BUF = 4 * T256_REGION;       // A0 A1 B0 B1
+constexpr int T256_SMEM = 2 * T256_BUF;         // 131072
+
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  int tm, tn;
+  block_to_tile(p, blockIdx.x, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int z = blockIdx.z;
+  const __bf16* A = p.A + (int64_t)z * p.sA;
+  const int nk = p.K >> 6;
+
+  // ---- staging sources: region h, round r -> rows 8*(r*8 + wave) + (lane>>3) of the region -------------------
+  const __bf16* gsrc[2][2][2];  // [A|B][region][round]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = (r * 8 + wave) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      gsrc[0][h][r] = A + (int64_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + chunk * 8;
+      gsrc[1][h][r] = p.W + (int64_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + chunk * 8;
+    }
+  auto stage = [&](int buf, int which, int h, int kt) {   // which: 0 = A, 1 = B
+    const int64_t koff = (int64_t)min(kt, nk - 1) * 64;
+    char* base = smem + buf * T256_BUF + (which * 2 + h) * T256_REGION + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[which][h][0] + koff), (lptr_t)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[which][h][1] + koff), (lptr_t)(base + 8 * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets -------------------------------------------------------------------------------------
+  const int fr = lane & 15, fq = lane >> 4;
+  const int a_base = (wr * 64 + fr) * 128, b_base = (wc * 32 + fr) * 128;
+  const int sw0 = ((0 + fq) ^ (fr >> 1)) * 16, sw1 = ((4 + fq) ^ (fr >> 1)) * 16;
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+  const bool interior = tile_is_interior(p, m0, n0, 256, 256);
+  const bool fold_res = interior && (p.epi & ICL_EPI_RESIDUAL) && p.res_dtype == ICL_F32 && !(p.epi & (ICL_EPI_GELU | ICL_EPI_SWIGLU));
+
+  auto read_a = [&](int buf, int h) {
+    const char* r = smem + buf * T256_BUF + h * T256_REGION + a_base;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *(const bf16x8*)(r + i * 2048 + sw0);
+      af[i][1] = *(const bf16x8*)(r + i * 2048 + sw1);
+    }
+  };
+  auto read_b = [&](int buf, int h, bf16x8 (&bf)[2][2]) {
+    const char* r = smem + buf * T256_BUF + (2 + h) * T256_REGION + b_base;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf[j][0] = *(const bf16x8*)(r + j * 2048 + sw0);
+      bf[j][1] = *(const bf16x8*)(r + j * 2048 + sw1);
+    }
+  };
+  auto mma = [&](f32x4 (&c)[4][2], bf16x8 (&bf)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], c[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto phase_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto tile = [&](int buf, int t) {
+    // P0
+    read_a(buf, 0);
+    read_b(buf, 0, b0f);
+    stage(buf ^ 1, 1, 1, t + 1);
+    phase_sync();
+    mma(acc[0][0], b0f);
+    // P1
+    read_b(buf, 1, b1f);
+    stage(buf ^ 1, 0, 1, t + 1);
+    phase_sync();
+    mma(acc[0][1], b1f);
+    // P2
+    read_a(buf, 1);
+    stage(buf, 0, 0, t + 2);
+    phase_sync();
+    mma(acc[1][1], b1f);
+    // P3
+    stage(buf, 1, 0, t + 2);
+    phase_sync();
+    mma(acc[1][0], b0f);
+  };
+
+  // accumulator init = (f32 residual) + bias: pure loads issued BEFORE the prologue's LDS-DMA, first use after it
+  f32x4 bias_f[2][2];
+  if (interior) {
+    if (fold_res) {
+#pragma unroll
+      for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[qa][qb][i][j] = *(const f32x4*)((const float*)p.R + (int64_t)z * p.sR +
+                                                  (int64_t)(m0 + qa * 128 + wr * 64 + i * 16 + fr) * p.ldr + n0 + qb * 128 +
+                                                  wc * 32 + j * 16 + fq * 4);
+    }
+    if (p.epi & ICL_EPI_BIAS) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bias_f[qb][j] = *(const f32x4*)(p.bias + n0 + qb * 128 + wc * 32 + j * 16 + fq * 4);
+    }
+  }
+  // prologue: A0(0) B0(0) B1(0) A1(0) A0(1) B0(1), then the uniform wait
+  __builtin_amdgcn_sched_barrier(0);
+  stage(0, 0, 0, 0);
+  stage(0, 1, 0, 0);
+  stage(0, 1, 1, 0);
+  stage(0, 0, 1, 0);
+  stage(1, 0, 0, 1);
+  stage(1, 1, 0, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  if (interior && (p.epi & ICL_EPI_BIAS)) {   // first use of the pre-loaded operands: ONE wait covers loads and prologue
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[qa][qb][i][j] = acc[qa][qb][i][j] + bias_f[qb][j];
+  }
+  phase_sync();
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    tile(0, t);
+    tile(1, t + 1);
+  }
+  if (t < nk) tile(0, t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail re-loads before the block retires
+
+  if (interior) {
+    const bool late_res = (p.epi & ICL_EPI_RESIDUAL) && !fold_res;
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa) {
+      const int mb = m0 + qa * 128 + wr * 64 + fr;
+      if (p.epi & ICL_EPI_SWIGLU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(acc[qa][qb][i][0][r]) * acc[qa][qb][i][1][r];
+            store_out4(p, (int64_t)z * p.sC + (int64_t)(mb + i * 16) * p.ldc + ((n0 + qb * 128 + wc * 32) >> 1) + fq * 4, v);
+          }
+        continue;
+      }
+      f32x4 rv[2][4][2];
+      if (late_res) {   // one batch of 16 independent loads per half tile
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              rv[qb][i][j] = load_res4(p, (int64_t)z * p.sR + (int64_t)(mb + i * 16) * p.ldr + n0 + qb * 128 + wc * 32 + j * 16 + fq * 4);
+      }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            f32x4 v = acc[qa][qb][i][j];
+            if (p.epi & ICL_EPI_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (late_res) v = v + rv[qb][i][j];
+            store_out4(p, (int64_t)z * p.sC + (int64_t)(mb + i * 16) * p.ldc + n0 + qb * 128 + wc * 32 + j * 16 + fq * 4, v);
+          }
+    }
+    return;
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + qa * 128 + wr * 64 + i * 16 + fr;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int nt = n0 + qb * 128 + wc * 32;
+        if (p.epi & ICL_EPI_SWIGLU) {
+          epi_store_swiglu(p, z, m, nt, fq * 4, acc[qa][qb][i][0], acc[qa][qb][i][1]);
+        } else {
+          epi_store4(p, z, m, nt + fq * 4, acc[qa][qb][i][0]);
+          epi_store4(p, z, m, nt + 16 + fq * 4, acc[qa][qb][i][1]);
+        }
+      }
+    }
+}
+
+int launch_tile256(GemmParams& p, int batch, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T256_SMEM);
+    if (e != hipSuccess) {
+      icl_set_error("icl_gemm_bf16: hipFuncSetAttribute(%d) failed: %s", T256_SMEM, hipGetErrorString(e));
+      return ICL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(p.tiles_m * p.tiles_n, 1, batch), dim3(512), T256_SMEM, stream, p);
+  ICL_CHECK_LAUNCH("icl_gemm_bf16(256)");
+  return ICL_OK;
+}
+
 template <int WAVES_M, int WAVES_N, int MI, int NI>
 int launch_tile(GemmParams& p, int batch, hipStream_t stream) {
   constexpr int BM = WAVES_M * MI * 16, BN = WAVES_N * NI * 16;
@@ -340,6 +670,25 @@ int launch_tile(GemmParams& p, int batch, hipStream_t stream) {
 }
 
 }  // namespace
+
+
+// Tile choice (measured on MI355X, profiles/r01_*):  64x64 for skinny / under-filled problems (and all split-K
+// calls), the 256x256 rolling pipeline when K is deep enough to amortise its fill/drain and the tile grid
+// quantises well onto the CUs (one 256x256 block per CU; K >= 1024 after the accumulator-init epilogue), otherwise the 128x128 double-buffered kernel.
+extern "C" int icl_gemm_select_tile(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t split_k) {
+  const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  if (split_k > 1 || M <= 64 || t128 < 256) return 2;
+  static int ncu = 0;
+  if (ncu <= 0) {
+    ncu = icl_device_cu_count();
+    if (ncu <= 0) ncu = 256;
+  }
+  const int64_t t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch;
+  const int64_t rounds = (t256 + ncu - 1) / ncu;
+  const double eff = (double)t256 / (double)(rounds * ncu);
+  if (K >= 1024 && eff >= 0.8) return 3;
+  return 1;
+}
 
 extern "C" int icl_gemm_bf16(const icl_gemm_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -400,17 +749,16 @@ extern "C" int icl_gemm_bf16(const icl_gemm_args* a, void* stream_) {
   p.tiles_m = p.tiles_n = 0;
 
   int tile = a->tile;
-  if (tile == 0) {
-    // 128x128 unless the problem is skinny or would leave most CUs idle
-    const int64_t t128 = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
-    tile = (a->M <= 64 || t128 < 256) ? 2 : 1;
-  }
+  if (tile == 0) tile = icl_gemm_select_tile(a->M, a->N, a->K, a->batch, a->split_k);
   int rc;
   if (tile == 1)
     rc = launch_tile<2, 2, 4, 4>(p, a->batch, stream);
   else if (tile == 2)
     rc = launch_tile<2, 2, 2, 2>(p, a->batch, stream);
-  else {
+  else if (tile == 3) {
+    ICL_CHECK_ARG(a->split_k == 1, "icl_gemm_bf16: the 256x256 tile does not support split_k");
+    rc = launch_tile256(p, a->batch, stream);
+  } else {
     icl_set_error("icl_gemm_bf16: unsupported tile id %d", tile);
     return ICL_EINVAL;
   }

@@ -1,5 +1,5 @@
-// norm.hip — LayerNorm / RMSNorm for gfx950 (HBM-bound; one 256-thread block per row).
-// The row lives in registers between the statistics passes (no re-read): each thread owns up to
+// norm.hip — LayerNorm / RMSNorm for gfx950 (HBM-bound; one 64-lane wave per row, 4 rows per block).
+// The row lives in registers between the statistics passes (no re-read): each lane owns up to
 // MAXV 4-element vectors (16 B f32 / 8 B bf16 loads, cdna_hip_programming.md Guideline 13).
 // Statistics are two-pass in f32 (mean, then sum of squared deviations), matching torch's
 // LayerNorm numerics more closely than E[x^2]-mean^2.
@@ -8,16 +8,7 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int MAXV = 8;  // N <= NT*4*MAXV = 8192
-
-__device__ __forceinline__ float block_sum(float v, float* red) {
-  v = wave_reduce_sum(v);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __syncthreads();  // protect red[] reuse between consecutive reductions
-  if (lane == 0) red[w] = v;
-  __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
-}
+constexpr int MAXN = 8192;  // 64 lanes x 4 x 32 chunks
 
 __device__ __forceinline__ f32x4 load4(const void* base, int64_t off, int dtype) {
   if (dtype == ICL_F32) return *(const f32x4*)((const float*)base + off);
@@ -34,20 +25,23 @@ __device__ __forceinline__ void store4(void* base, int64_t off, int dtype, f32x4
   }
 }
 
-template <bool RMS>
+// One WAVE per row (4 rows per block): the row lives in registers, both statistics are shuffle-only
+// reductions — no LDS, no barrier.  MAXV = float4 chunks per lane (N <= 64*4*MAXV).
+template <bool RMS, int MAXV>
 __global__ __launch_bounds__(NT) void norm_kernel(const void* x, int64_t ldx, const void* res,
                                                    float alpha, const float* gamma,
                                                    const float* beta, void* y, int64_t ldy,
-                                                   void* y2, int64_t ldy2, int N, float eps,
+                                                   void* y2, int64_t ldy2, int M, int N, float eps,
                                                    int in_dtype, int out_dtype) {
-  __shared__ float red[4];
-  const int64_t m = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
   const int nvec = N >> 2;
   f32x4 v[MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = threadIdx.x + i * NT;
+    const int c = lane + i * 64;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < nvec) {
       v[i] = load4(x, m * ldx + c * 4, in_dtype);
@@ -61,14 +55,13 @@ __global__ __launch_bounds__(NT) void norm_kernel(const void* x, int64_t ldx, co
   }
   float mean = 0.f, rstd;
   if (RMS) {
-    const float ss = block_sum(s, red);
-    rstd = rsqrtf(ss / (float)N + eps);
+    rstd = rsqrtf(wave_reduce_sum(s) / (float)N + eps);
   } else {
-    mean = block_sum(s, red) / (float)N;
+    mean = wave_reduce_sum(s) / (float)N;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = threadIdx.x + i * NT;
+      const int c = lane + i * 64;
       if (c < nvec) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -77,11 +70,11 @@ __global__ __launch_bounds__(NT) void norm_kernel(const void* x, int64_t ldx, co
         }
       }
     }
-    rstd = rsqrtf(block_sum(q, red) / (float)N + eps);
+    rstd = rsqrtf(wave_reduce_sum(q) / (float)N + eps);
   }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = threadIdx.x + i * NT;
+    const int c = lane + i * 64;
     if (c < nvec) {
       const f32x4 g = *(const f32x4*)(gamma + c * 4);
       f32x4 o;
@@ -97,12 +90,26 @@ __global__ __launch_bounds__(NT) void norm_kernel(const void* x, int64_t ldx, co
   }
 }
 
+template <bool RMS>
+void launch_norm(hipStream_t st, const void* x, int64_t ldx, const void* res, float alpha, const float* gamma,
+                 const float* beta, void* y, int64_t ldy, void* y2, int64_t ldy2, int M, int N, float eps,
+                 int in_dtype, int out_dtype) {
+  const dim3 grid((M + 3) / 4), block(NT);
+  const int per_lane = ((N >> 2) + 63) / 64;
+  if (per_lane <= 8)
+    hipLaunchKernelGGL((norm_kernel<RMS, 8>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, N, eps, in_dtype, out_dtype);
+  else if (per_lane <= 16)
+    hipLaunchKernelGGL((norm_kernel<RMS, 16>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, N, eps, in_dtype, out_dtype);
+  else
+    hipLaunchKernelGGL((norm_kernel<RMS, 32>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, N, eps, in_dtype, out_dtype);
+}
+
 int check_common(const char* name, const void* x, int64_t ldx, const float* gamma, void* y,
                  int64_t ldy, int M, int N, int in_dtype, int out_dtype) {
   ICL_CHECK_ARG(x && gamma && y, "%s: NULL pointer", name);
   ICL_CHECK_ARG(M > 0 && N > 0, "%s: M,N must be > 0", name);
-  ICL_CHECK_ARG(N % 4 == 0 && N <= NT * 4 * MAXV, "%s: N=%d must be a multiple of 4 and <= %d", name, N,
-                NT * 4 * MAXV);
+  ICL_CHECK_ARG(N % 4 == 0 && N <= MAXN, "%s: N=%d must be a multiple of 4 and <= %d", name, N,
+                MAXN);
   ICL_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= N && ldy >= N, "%s: bad leading dimensions", name);
   ICL_CHECK_ARG((in_dtype == ICL_F32 || in_dtype == ICL_BF16) && (out_dtype == ICL_F32 || out_dtype == ICL_BF16),
                 "%s: bad dtype", name);
@@ -123,8 +130,7 @@ extern "C" int icl_layernorm(const void* x, int64_t ldx, const void* res, float 
   ICL_CHECK_ARG(beta && ((uintptr_t)beta % 16) == 0, "icl_layernorm: beta NULL or misaligned");
   if (y2) ICL_CHECK_ARG(ldy2 % 4 == 0 && ldy2 >= N && ((uintptr_t)y2 % 8) == 0, "icl_layernorm: bad y2");
   if (res) ICL_CHECK_ARG(((uintptr_t)res % (in_dtype == ICL_F32 ? 16 : 8)) == 0, "icl_layernorm: res misaligned");
-  hipLaunchKernelGGL(norm_kernel<false>, dim3(M), dim3(NT), 0, (hipStream_t)stream, x, ldx, res, alpha,
-                     gamma, beta, y, ldy, y2, ldy2, N, eps, in_dtype, out_dtype);
+  launch_norm<false>((hipStream_t)stream, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, N, eps, in_dtype, out_dtype);
   ICL_CHECK_LAUNCH("icl_layernorm");
   return ICL_OK;
 }
@@ -134,9 +140,7 @@ extern "C" int icl_rmsnorm(const void* x, int64_t ldx, const float* gamma, void*
                            void* stream) {
   int rc = check_common("icl_rmsnorm", x, ldx, gamma, y, ldy, M, N, in_dtype, out_dtype);
   if (rc) return rc;
-  hipLaunchKernelGGL(norm_kernel<true>, dim3(M), dim3(NT), 0, (hipStream_t)stream, x, ldx,
-                     (const void*)nullptr, 0.f, gamma, (const float*)nullptr, y, ldy, (void*)nullptr,
-                     (int64_t)0, N, eps, in_dtype, out_dtype);
+  launch_norm<true>((hipStream_t)stream, x, ldx, nullptr, 0.f, gamma, nullptr, y, ldy, nullptr, 0, M, N, eps, in_dtype, out_dtype);
   ICL_CHECK_LAUNCH("icl_rmsnorm");
   return ICL_OK;
 }

@@ -22,7 +22,7 @@ ABI_VERSION = 1
 
 
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
-# entries are (tile, split_k, algorithmic_flops, start_event, end_event)
+# entries are (tile, split_k, algorithmic_flops, start_event, end_event, (M, N, K, batch))
 GEMM_PROFILE = None
 
 
@@ -57,6 +57,7 @@ _SIGNATURES = {
     "icl_last_error": (c_char_p, []),
     "icl_device_cu_count": (c_int, []),
     "icl_gemm_bf16": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "icl_gemm_select_tile": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "icl_attn_fwd_bf16": (c_int, [POINTER(AttnArgs), c_void_p]),
     "icl_attn_decode_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                      c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
@@ -180,9 +181,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, resi
     g.out_dtype = _dt(out)
     g.res_dtype = _dt(residual) if residual is not None else ICL_F32
     g.split_k = split_k
-    if tile == 0:  # same rule as the library's auto choice, made here so a profiler hook knows the kernel
-        t128 = ((g.M + 127) // 128) * ((N + 127) // 128) * batch
-        tile = 2 if (g.M <= 64 or t128 < 256) else 1
+    if tile == 0:  # resolve the library's auto choice here so a profiler hook knows which kernel ran
+        tile = lib.icl_gemm_select_tile(g.M, N, g.K, batch, split_k)
     g.tile = tile
     if split_k > 1 and workspace is not None:
         assert workspace.dtype == torch.float32 and workspace.numel() >= split_k * g.M * N
@@ -191,7 +191,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, resi
         e0.record()
         _check(lib.icl_gemm_bf16(ctypes.byref(g), _stream()), "icl_gemm_bf16")
         e1.record()
-        GEMM_PROFILE.append((tile, split_k, 2.0 * g.M * N * g.K * batch, e0, e1))
+        GEMM_PROFILE.append((tile, split_k, 2.0 * g.M * N * g.K * batch, e0, e1, (g.M, N, g.K, batch)))
         return out
     _check(lib.icl_gemm_bf16(ctypes.byref(g), _stream()), "icl_gemm_bf16")
     return out

@@ -257,7 +257,7 @@ def pack_qformer(sd: SD, cfg: QFormerCfg, device, consume: bool = False) -> Pack
 class LlamaLayer:
     rms1: torch.Tensor
     wqkv: torch.Tensor           # [3h, K_aug]
-    lora_a: Optional[torch.Tensor]  # [2r, h]
+    lora_a: Optional[torch.Tensor]  # [2r, h], pre-multiplied by alpha/r
     wo: torch.Tensor
     rms2: torch.Tensor
     wgu: torch.Tensor            # [2*ffn, h] interleaved in blocks of 16
@@ -294,7 +294,8 @@ def pack_llama(sd: SD, cfg: LlamaCfg, device, prefix: str = "llama_model.", cons
             bq, bv = _take(sd, lp + "self_attn.q_proj.lora_B.weight", consume), _take(sd, lp + "self_attn.v_proj.lora_B.weight", consume)
             wqkv[0:h, h:h + r] = bq.to(device=device, dtype=torch.bfloat16)
             wqkv[2 * h:3 * h, h + r:h + 2 * r] = bv.to(device=device, dtype=torch.bfloat16)
-            lora_a = _bf(torch.cat([aq, av], 0), device)
+            # the LoRA scale (alpha/r) is folded into A here so the down-projection can run as a plain GEMM
+            lora_a = _bf(torch.cat([aq, av], 0).float() * cfg.lora_scale, device)
         g = _take(sd, lp + "mlp.gate_proj.weight", consume).to(device=device, dtype=torch.bfloat16)
         u = _take(sd, lp + "mlp.up_proj.weight", consume).to(device=device, dtype=torch.bfloat16)
         wgu = torch.stack([g.view(I // 16, 16, h), u.view(I // 16, 16, h)], dim=1).reshape(2 * I, h).contiguous()

@@ -87,10 +87,12 @@ typedef struct icl_gemm_args {
   int32_t out_dtype;    /* ICL_BF16 | ICL_F32              */
   int32_t res_dtype;    /* ICL_BF16 | ICL_F32              */
   int32_t split_k;      /* >= 1                            */
-  int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (skinny / decode), 3 = 256x256 */
+  int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (skinny / decode), 3 = 256x256 (no split_k) */
 } icl_gemm_args;
 
 int icl_gemm_bf16(const icl_gemm_args* args, void* stream);
+/* The tile id (1|2|3) that tile == 0 resolves to for this problem (pure host function). */
+int icl_gemm_select_tile(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t split_k);
 
 /* ---- K3/K5/K10/K13/K14: fused (flash-style) attention forward ---------------------------
  * O[t][h][:] = softmax_j( scale * Q[t][h]·K[j][h] + bias ) · V[j][h]   per packed sequence.

@@ -30,13 +30,17 @@ def bench_gemm():
         (6016, 22016, 4096, "llama gate/up B=16"), (6016, 4096, 11008, "llama down B=16"),
         (376, 4096, 4096, "llama o    B=1"), (24000, 3840, 1280, "whisper qkv B=16"),
         (24000, 5120, 1280, "whisper fc1 B=16"), (24000, 1280, 5120, "whisper fc2 B=16"),
+        (12032, 12288, 4160, "llama qkv  B=32"), (12032, 4096, 4096, "llama o    B=32"),
+        (12032, 22016, 4096, "llama gate/up B=32"), (12032, 4096, 11008, "llama down B=32"),
+        (48000, 3840, 1280, "whisper qkv B=32"), (48000, 1280, 1280, "whisper o  B=32"),
+        (48000, 5120, 1280, "whisper fc1 B=32"), (48000, 1280, 5120, "whisper fc2 B=32"),
         (4096, 4096, 4096, "4096^3"), (8192, 8192, 8192, "8192^3"),
     ]
     for M, N, K, tag in shapes:
         a = torch.randn(M, K, device=DEV).to(torch.bfloat16)
         w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
         out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        for tile in (1, 2):
+        for tile in (1, 3):
             t = timeit(lambda: B.gemm(a, w, out, tile=tile))
             print(f"gemm tile={tile} {tag:22s} M={M:6d} N={N:6d} K={K:6d}  {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
         t = timeit(lambda: torch.matmul(a, w.t()))
