@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="utterances per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="miniature model (smoke only; not a valid bench number)")

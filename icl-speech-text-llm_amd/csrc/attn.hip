@@ -10,7 +10,7 @@
 //     k-permuted V^T A-operand comes from two ds_read_b64_tr_b16 transposed reads of the
 //     row-major V tile.  The per-query rescale is then a per-lane scalar.
 //   * K/V tiles are register-staged (global -> VGPR issued before the compute of the current
-//     tile, ds_write after the barrier: T14), rows padded (K: +16 B, V: +64 B) so that both the
+//     tile, ds_write into the OTHER LDS buffer after it: T14; one barrier per tile), rows padded (K: +16 B, V: +64 B) so that both the
 //     ds_read_b128 K-fragment reads and the transposed V reads are bank-conflict free.
 // Variable-length packing (cu_seqlens), causal masking, a key-padding length per sequence and the
 // BEATs gated relative-position bias are handled in the score stage.
@@ -43,9 +43,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int DB = D / 32;        // output d-blocks
   constexpr int CPR = D / 8;        // 16-B chunks per row
   constexpr int NCH = 64 * CPR / 256;  // staging chunks per thread per tensor
-  __shared__ __attribute__((aligned(16))) char lds[64 * KSTR + 64 * VSTR];
-  char* k_lds = lds;
-  char* v_lds = lds + 64 * KSTR;
+  constexpr int BUF = 64 * KSTR + 64 * VSTR;   // one K tile + one V tile
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];   // double-buffered: ONE barrier per KV tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hh = lane >> 5;
@@ -90,13 +89,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       vreg[i] = *(const u32x4*)(p.V + grow * p.ldv + head * D + cc * 8);
     }
   };
-  auto write_tile = [&]() {
+  auto write_tile = [&](int buf) {
+    char* k_w = lds + buf * BUF;
+    char* v_w = k_w + 64 * KSTR;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * 256;
       const int r = c / CPR, cc = c - r * CPR;
-      *(u32x4*)(k_lds + r * KSTR + cc * 16) = kreg[i];
-      *(u32x4*)(v_lds + r * VSTR + cc * 16) = vreg[i];
+      *(u32x4*)(k_w + r * KSTR + cc * 16) = kreg[i];
+      *(u32x4*)(v_w + r * VSTR + cc * 16) = vreg[i];
     }
   };
 
@@ -111,12 +112,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const int tr_lane_off = ((lane & 15) >> 2) * VSTR + ((((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
 
   load_tile(0);
-  write_tile();
+  write_tile(0);
   __syncthreads();
 
   for (int t = 0; t < n_tiles; ++t) {
     if (t + 1 < n_tiles) load_tile(t + 1);
     const int k0 = t * 64;
+    const char* k_lds = lds + (t & 1) * BUF;
+    const char* v_lds = k_lds + 64 * KSTR;
     // wave-uniform: does this wave have any visible key in this tile?
     const bool active = !CAUSAL || (k0 <= qw + 31);
     if (active) {
@@ -134,41 +137,60 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
       }
       // ---- scores -> base-2 logits, bias, mask -----------------------------------------------------
-      const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw));
-      float tmax = NEG_BIG;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          float v = s_acc[kb][r] * p.scale_log2e;
-          if (BIAS) {
-            int rel = key - qpos;
-            rel = max(-(p.rel_span - 1), min(p.rel_span - 1, rel));
-            v += gate * bias_row[rel];
-          }
-          if (need_mask) {
-            const bool ok = (key < kvlen) && (!CAUSAL || key <= qpos);
-            v = ok ? v : NEG_BIG;
-          }
-          s_acc[kb][r] = v;
-          tmax = fmaxf(tmax, v);
-        }
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = exp2f(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.f;
+      // need_mask is wave-uniform: interior tiles take the branch-free fast path (raw v_exp_f32, one FMA per score)
+      const bool need_mask = __builtin_amdgcn_readfirstlane((int)((k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw))));
+      float psum = 0.f, alpha;
       bf16x8 pf[2][2];
+      if (!BIAS && !need_mask) {
+        float tmax = fmaxf(s_acc[0][0], s_acc[1][0]);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s_acc[0][r], s_acc[1][r]));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;
+        const float m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float e = exp2f(s_acc[kb][r] - m_new);
-          if (need_mask) e = (s_acc[kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
-          psum += e;
-          pf[kb][r >> 3][r & 7] = (__bf16)e;
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[kb][r], p.scale_log2e, -m_new));
+            psum += e;
+            pf[kb][r >> 3][r & 7] = (__bf16)e;
+          }
+      } else {
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float v = s_acc[kb][r] * p.scale_log2e;
+            if (BIAS) {
+              int rel = key - qpos;
+              rel = max(-(p.rel_span - 1), min(p.rel_span - 1, rel));
+              v += gate * bias_row[rel];
+            }
+            if (need_mask) {
+              const bool ok = (key < kvlen) && (!CAUSAL || key <= qpos);
+              v = ok ? v : NEG_BIG;
+            }
+            s_acc[kb][r] = v;
+            tmax = fmaxf(tmax, v);
+          }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float e = __builtin_amdgcn_exp2f(s_acc[kb][r] - m_new);
+            if (need_mask) e = (s_acc[kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
+            psum += e;
+            pf[kb][r >> 3][r & 7] = (__bf16)e;
+          }
         }
       }
       l_run = l_run * alpha + psum;
@@ -194,11 +216,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
       }
     }
+    // the other buffer was last read in iteration t-1, and every wave has passed the barrier that ended it
+    if (t + 1 < n_tiles) write_tile((t + 1) & 1);
     __syncthreads();
-    if (t + 1 < n_tiles) {
-      write_tile();
-      __syncthreads();
-    }
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l -------------------------------------------------------------

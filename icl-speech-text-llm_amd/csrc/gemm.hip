@@ -475,6 +475,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
       bf[j][1] = *(const bf16x8*)(r + j * 2048 + sw1);
     }
   };
+  // MFMA cluster of one phase, closed by the phase's SECOND barrier.  The two wave groups (wr = 0 / 1) run one barrier
+  // apart (see the stagger below), so between two consecutive barriers one group issues its 16 MFMAs while the other
+  // issues its LDS reads + LDS-DMA + waits: matrix pipe and LDS/VMEM overlap on every SIMD (2 waves/SIMD, one per group).
   auto mma = [&](f32x4 (&c)[4][2], bf16x8 (&bf)[2][2]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -485,6 +488,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
         for (int j = 0; j < 2; ++j)
           c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], c[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto phase_sync = [&]() {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -558,12 +564,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
           for (int j = 0; j < 2; ++j) acc[qa][qb][i][j] = acc[qa][qb][i][j] + bias_f[qb][j];
   }
   phase_sync();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0 (hazard analysis in DESIGN.md §4)
   int t = 0;
   for (; t + 1 < nk; t += 2) {
     tile(0, t);
     tile(1, t + 1);
   }
   if (t < nk) tile(0, t);
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count of the two groups
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail re-loads before the block retires
 
   if (interior) {

@@ -95,13 +95,17 @@ void launch_norm(hipStream_t st, const void* x, int64_t ldx, const void* res, fl
                  const float* beta, void* y, int64_t ldy, void* y2, int64_t ldy2, int M, int N, float eps,
                  int in_dtype, int out_dtype) {
   const dim3 grid((M + 3) / 4), block(NT);
-  const int per_lane = ((N >> 2) + 63) / 64;
-  if (per_lane <= 8)
-    hipLaunchKernelGGL((norm_kernel<RMS, 8>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, N, eps, in_dtype, out_dtype);
-  else if (per_lane <= 16)
-    hipLaunchKernelGGL((norm_kernel<RMS, 16>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, N, eps, in_dtype, out_dtype);
-  else
-    hipLaunchKernelGGL((norm_kernel<RMS, 32>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, N, eps, in_dtype, out_dtype);
+  const int per_lane = ((N >> 2) + 63) / 64;   // float4 chunks per lane; exact-fit instantiations keep VGPRs (and so occupancy) tight
+#define ICL_NORM_CASE(V)                                                                                             \
+  hipLaunchKernelGGL((norm_kernel<RMS, V>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, N, \
+                     eps, in_dtype, out_dtype)
+  if (per_lane <= 3) ICL_NORM_CASE(3);         // N <= 768  (BEATs, Q-Former)
+  else if (per_lane <= 5) ICL_NORM_CASE(5);    // N <= 1280 (Whisper)
+  else if (per_lane <= 8) ICL_NORM_CASE(8);    // N <= 2048
+  else if (per_lane <= 16) ICL_NORM_CASE(16);  // N <= 4096 (Llama-7B)
+  else if (per_lane <= 20) ICL_NORM_CASE(20);  // N <= 5120 (Llama-13B)
+  else ICL_NORM_CASE(32);
+#undef ICL_NORM_CASE
 }
 
 int check_common(const char* name, const void* x, int64_t ldx, const float* gamma, void* y,
