@@ -210,9 +210,19 @@ def main():
         all_t = sum(v[1] for v in per_tile.values())
         dom = max(per_tile, key=lambda k: per_tile[k][1])          # dominant kernel = largest share of GPU time
         fl, tt, n = per_tile[dom]
+        traffic = None
+        try:   # HBM-side bytes per launch of this kernel from the committed PMC passes of this same command (profiles/)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = {1: "gemm_bf16_kernel<2, 2, 4, 4>", 2: "gemm_bf16_kernel<2, 2, 2, 2>", 3: "gemm256_bf16_kernel"}[dom]
+            if f"(batch {Bm})" in pmc["command"] and not args.tiny:
+                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": names.get(dom, str(dom)), "achieved": round(fl / tt / 1e12, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4),
-                "traffic": None, "launches": n, "avg_launch_us": round(tt / n * 1e6, 2),
+                "traffic": traffic, "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (KiB) from separate rocprofv3 --pmc "
+                "passes of this command (profiles/r01_pmc_traffic.json); the counters sit at the L2<->fabric boundary and "
+                "include Infinity-Cache hits" if traffic else None, "launches": n, "avg_launch_us": round(tt / n * 1e6, 2),
                 "avg_launch_gflop": round(fl / n / 1e9, 3), "share_of_step_time": round(tt / elapsed, 3),
                 "all_gemm_share_of_step_time": round(all_t / elapsed, 3),
                 "other_gemm_kernels": {names.get(k, str(k)): {"achieved_tflops": round(v[0] / v[1] / 1e12, 1),
