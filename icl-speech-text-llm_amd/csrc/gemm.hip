@@ -139,10 +139,15 @@ __device__ __forceinline__ void store_out4(const GemmParams& p, int64_t coff, f3
     *(f32x4*)((char*)p.C + coff * 4) = v;
   }
 }
-__device__ __forceinline__ bool tile_is_interior(const GemmParams& p, int m0, int n0, int BM, int BN) {
+// Tile-INDEPENDENT vector-path predicate: whether a row's arithmetic order (accumulator init = bias + residual) may
+// depend only on the problem, never on which tile of the grid the row falls in -> results are batch-invariant.
+__device__ __forceinline__ bool vec_path_ok(const GemmParams& p) {
   const bool has_res = p.epi & ICL_EPI_RESIDUAL;
-  return (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldc & 3) == 0) && (!has_res || (p.ldr & 3) == 0) &&
+  return ((p.ldc & 3) == 0) && ((p.N & 3) == 0) && (!has_res || (p.ldr & 3) == 0) &&
          (!(p.epi & ICL_EPI_BIAS) || (((uintptr_t)p.bias & 15) == 0));
+}
+__device__ __forceinline__ bool tile_is_interior(const GemmParams& p, int m0, int n0, int BM, int BN) {
+  return (m0 + BM <= p.M) && (n0 + BN <= p.N) && vec_path_ok(p);
 }
 __device__ __forceinline__ void block_to_tile(const GemmParams& p, int bid, int& tm, int& tn) {
   const int nwg = p.tiles_m * p.tiles_n;
@@ -233,33 +238,38 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Interior tiles fold the epilogue operands into the accumulator INIT: acc = bias (+ residual when no activation
-  // follows), loaded while the first K-tile is in flight, so no dependent global load is left after the K loop.
-  const bool interior = p.split_k == 1 && tile_is_interior(p, m0, n0, BM, BN);
-  const bool fold_res = interior && (p.epi & ICL_EPI_RESIDUAL) && p.res_dtype == ICL_F32 && !(p.epi & (ICL_EPI_GELU | ICL_EPI_SWIGLU));
+  // The epilogue operands are folded into the accumulator INIT: acc = bias (+ f32 residual when no activation follows),
+  // loaded while the first K-tile is in flight, so no dependent global load is left after the K loop.  The fold
+  // decision is tile-independent (vec_path_ok); edge tiles only add bounds guards to the same loads.
+  const bool vecp = p.split_k == 1 && vec_path_ok(p);
+  const bool interior = vecp && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const bool fold_bias = vecp && (p.epi & ICL_EPI_BIAS);
+  const bool fold_res = vecp && (p.epi & ICL_EPI_RESIDUAL) && p.res_dtype == ICL_F32 && !(p.epi & (ICL_EPI_GELU | ICL_EPI_SWIGLU));
 
   // order matters: pure loads first (no use -> no wait), then the LDS-DMA of K-tile 0, then the first use (one wait
   // that covers everything); a use placed between loads would make hipcc drain vmcnt(0) per load.
   f32x4 bias_f[NI];
-  if (interior) {
-    if (fold_res && p.res_dtype == ICL_F32) {
-      const int mb = m0 + wm * MI * 16 + fr, nb = n0 + wn * NI * 16 + fq * 4;
+  {
+    const int mb = m0 + wm * MI * 16 + fr, nb = n0 + wn * NI * 16 + fq * 4;
+    if (fold_res) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = *(const f32x4*)((const float*)p.R + (int64_t)z * p.sR + (int64_t)(mb + i * 16) * p.ldr + nb + j * 16);
+          if (interior || (mb + i * 16 < p.M && nb + j * 16 < p.N))
+            acc[i][j] = *(const f32x4*)((const float*)p.R + (int64_t)z * p.sR + (int64_t)(mb + i * 16) * p.ldr + nb + j * 16);
     }
-    if (p.epi & ICL_EPI_BIAS) {
+    if (fold_bias) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bias_f[j] = *(const f32x4*)(p.bias + n0 + wn * NI * 16 + j * 16 + fq * 4);
+      for (int j = 0; j < NI; ++j)
+        bias_f[j] = (interior || nb + j * 16 < p.N) ? *(const f32x4*)(p.bias + nb + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   if (kt0 < kt1) {
     __builtin_amdgcn_sched_barrier(0);
     stage(0, kt0);
     __builtin_amdgcn_sched_barrier(0);
-    if (interior && (p.epi & ICL_EPI_BIAS)) {
+    if (fold_bias) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -331,6 +341,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       }
     return;
   }
+  GemmParams q = p;   // edge tiles: same arithmetic, bounds-checked stores; operands already folded are not re-applied
+  if (fold_bias) q.epi &= ~ICL_EPI_BIAS;
+  if (fold_res) q.epi &= ~ICL_EPI_RESIDUAL;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = m0 + wm * MI * 16 + i * 16 + fr;
@@ -341,10 +354,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         epi_store_partial(p, z, m, nt + fq * 4, acc[i][j]);
       } else if (p.epi & ICL_EPI_SWIGLU) {
         if constexpr (NI % 2 == 0) {
-          if ((j & 1) == 0) epi_store_swiglu(p, z, m, nt, fq * 4, acc[i][j], acc[i][j + 1]);
+          if ((j & 1) == 0) epi_store_swiglu(q, z, m, nt, fq * 4, acc[i][j], acc[i][j + 1]);
         }
       } else {
-        epi_store4(p, z, m, nt + fq * 4, acc[i][j]);
+        epi_store4(q, z, m, nt + fq * 4, acc[i][j]);
       }
     }
   }
@@ -456,8 +469,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[4][2], b0f[2][2], b1f[2][2];
-  const bool interior = tile_is_interior(p, m0, n0, 256, 256);
-  const bool fold_res = interior && (p.epi & ICL_EPI_RESIDUAL) && p.res_dtype == ICL_F32 && !(p.epi & (ICL_EPI_GELU | ICL_EPI_SWIGLU));
+  const bool vecp = vec_path_ok(p);
+  const bool interior = vecp && (m0 + 256 <= p.M) && (n0 + 256 <= p.N);
+  const bool fold_bias = vecp && (p.epi & ICL_EPI_BIAS);
+  const bool fold_res = vecp && (p.epi & ICL_EPI_RESIDUAL) && p.res_dtype == ICL_F32 && !(p.epi & (ICL_EPI_GELU | ICL_EPI_SWIGLU));
 
   auto read_a = [&](int buf, int h) {
     const char* r = smem + buf * T256_BUF + h * T256_REGION + a_base;
@@ -521,28 +536,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
     mma(acc[1][0], b0f);
   };
 
-  // accumulator init = (f32 residual) + bias: pure loads issued BEFORE the prologue's LDS-DMA, first use after it
+  // accumulator init = (f32 residual) + bias: pure loads issued BEFORE the prologue's LDS-DMA, first use after it;
+  // tile-independent decision (vec_path_ok), edge tiles only add bounds guards
   f32x4 bias_f[2][2];
-  if (interior) {
-    if (fold_res) {
+  if (fold_res) {
 #pragma unroll
-      for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[qa][qb][i][j] = *(const f32x4*)((const float*)p.R + (int64_t)z * p.sR +
-                                                  (int64_t)(m0 + qa * 128 + wr * 64 + i * 16 + fr) * p.ldr + n0 + qb * 128 +
-                                                  wc * 32 + j * 16 + fq * 4);
-    }
-    if (p.epi & ICL_EPI_BIAS) {
+    for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bias_f[qb][j] = *(const f32x4*)(p.bias + n0 + qb * 128 + wc * 32 + j * 16 + fq * 4);
-    }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int m = m0 + qa * 128 + wr * 64 + i * 16 + fr, n = n0 + qb * 128 + wc * 32 + j * 16 + fq * 4;
+            if (interior || (m < p.M && n < p.N))
+              acc[qa][qb][i][j] = *(const f32x4*)((const float*)p.R + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
+          }
+  }
+  if (fold_bias) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + qb * 128 + wc * 32 + j * 16 + fq * 4;
+        bias_f[qb][j] = (interior || n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
   }
   // prologue: A0(0) B0(0) B1(0) A1(0) A0(1) B0(1), then the uniform wait
   __builtin_amdgcn_sched_barrier(0);
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
   stage(1, 0, 0, 1);
   stage(1, 1, 0, 1);
   __builtin_amdgcn_sched_barrier(0);
-  if (interior && (p.epi & ICL_EPI_BIAS)) {   // first use of the pre-loaded operands: ONE wait covers loads and prologue
+  if (fold_bias) {   // first use of the pre-loaded operands: ONE wait covers loads and prologue
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
@@ -619,7 +637,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
     return;
   }
 
-  // ---- epilogue ----------------------------------------------------------------------------------------------------
+  // ---- edge tiles: same arithmetic, bounds-checked stores; operands already folded are not re-applied ----------------
+  GemmParams q = p;
+  if (fold_bias) q.epi &= ~ICL_EPI_BIAS;
+  if (fold_res) q.epi &= ~ICL_EPI_RESIDUAL;
 #pragma unroll
   for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
@@ -629,10 +650,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
       for (int qb = 0; qb < 2; ++qb) {
         const int nt = n0 + qb * 128 + wc * 32;
         if (p.epi & ICL_EPI_SWIGLU) {
-          epi_store_swiglu(p, z, m, nt, fq * 4, acc[qa][qb][i][0], acc[qa][qb][i][1]);
+          epi_store_swiglu(q, z, m, nt, fq * 4, acc[qa][qb][i][0], acc[qa][qb][i][1]);
         } else {
-          epi_store4(p, z, m, nt + fq * 4, acc[qa][qb][i][0]);
-          epi_store4(p, z, m, nt + 16 + fq * 4, acc[qa][qb][i][1]);
+          epi_store4(q, z, m, nt + fq * 4, acc[qa][qb][i][0]);
+          epi_store4(q, z, m, nt + 16 + fq * 4, acc[qa][qb][i][1]);
         }
       }
     }

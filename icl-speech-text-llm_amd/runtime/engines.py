@@ -300,9 +300,9 @@ class LlamaHIP:
         wsk = ws.get(tag + "splitk", (max(sk.values()) * M * max(3 * hd, 2 * I),), F32) if sk else None
         B.rmsnorm(h, L.rms1, xn, c.rms_eps, N=hd)
         if L.lora_a is not None:   # x_aug[:, hd:hd+2r] = x @ (s*A)^T : a skinny GEMM for prefill, a GEMV-style kernel for decode
-            if M > 256:
+            if split is None:   # prefill (any M: the choice must not depend on the batch, or rows would not be batch-invariant)
                 B.gemm(xn, L.lora_a, xn[:, hd:hd + 2 * c.lora_rank], K=hd, tile=2)
-            else:
+            else:               # decode
                 B.lora_down(xn, hd, L.lora_a, 2 * c.lora_rank, 1.0, M=M)
         B.gemm(xn, L.wqkv, qkv, split_k=sk.get("qkv", 1), workspace=wsk, tile=sk.get("tile", 0))
         B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)

@@ -1,0 +1,80 @@
+"""`-m gpu`: size-independent properties at the FULL BASELINE.json C2 shapes (Whisper-large-v2 + BEATs + Llama-2-7B dims,
+seeded random bf16 weights), where the CPU oracle is too slow to be the checker:
+
+  * batch invariance (bit-exact): an utterance's speech embeddings and prefill logits do not depend on what else is
+    packed in the batch (ragged packing, no padding);
+  * causality: logits at position t do not change when the tokens after t change;
+  * determinism: two runs give identical token ids; EOS-suppressed generation returns exactly max_new_tokens;
+  * K1 closed form: silence -> the analytically known constant log-mel.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from icl_speech_text_llm_amd.runtime import synth
+    from icl_speech_text_llm_amd.runtime.config import SalmonnCfg
+    from icl_speech_text_llm_amd.runtime.salmonn import SalmonnRuntime
+    cfg = SalmonnCfg.llama2_7b()
+    sd = synth.salmonn_state(cfg, seed=0, device="cuda", dtype=torch.bfloat16)
+    r = SalmonnRuntime(cfg, sd, device="cuda", consume=True)
+    del sd
+    return r
+
+
+def _wav(i, n):
+    return torch.from_numpy(np.clip(np.random.default_rng(1234 + i).normal(0, 0.1, n), -1, 1).astype(np.float32))
+
+
+def _ids(i, n):
+    return np.random.default_rng(99 + i).integers(3, 32000, n).tolist()
+
+
+def test_encode_speech_is_batch_invariant(rt):
+    lens = [480000, 16000 * 7 + 13, 480000]
+    wav = torch.zeros(3, 480000)
+    for i, n in enumerate(lens):
+        wav[i, :n] = _wav(i, n)
+    batch = rt.encode_speech(wav, lens).clone()
+    assert batch.shape == (3, 88, 4096) and torch.isfinite(batch).all()
+    for i, n in enumerate(lens):
+        solo = rt.encode_speech(wav[i:i + 1], [n])
+        assert torch.equal(solo[0], batch[i]), f"audio {i} depends on its batch neighbours"
+
+
+def test_prefill_logits_batch_invariant_and_causal(rt):
+    from icl_speech_text_llm_amd.runtime.salmonn import speech_segment
+    speech = torch.randn(2, 88, 4096, device="cuda") * 0.02
+    a, b = _ids(0, 288), _ids(1, 170)
+    pa = [a[:280], speech_segment(0, 88), a[280:]]
+    pb = [b[:100], speech_segment(88, 88), b[100:]]
+    both, lens = rt.forward_logits([pa, pb], speech)
+    both = both.clone()
+    assert lens == [376, 258] and torch.isfinite(both).all()
+    solo_a, _ = rt.forward_logits([pa], speech)
+    assert torch.equal(solo_a, both[:376])                       # bit-exact: packing is per-sequence independent
+    # causality: change the LAST 8 tokens of prompt a -> logits of all earlier positions are unchanged
+    a2 = a[:280] + [(t + 7) % 31000 + 3 for t in a[280:]]
+    alt, _ = rt.forward_logits([[a2[:280], speech_segment(0, 88), a2[280:]]], speech)
+    assert torch.equal(alt[:368], both[:368])
+    assert not torch.equal(alt[368:], both[368:376])
+
+
+def test_generate_is_deterministic_and_full_width(rt):
+    from icl_speech_text_llm_amd.runtime.salmonn import speech_segment
+    speech = torch.randn(1, 88, 4096, device="cuda") * 0.02
+    p = [[_ids(5, 280), speech_segment(0, 88), _ids(6, 8)]]
+    r1 = rt.generate(p, speech, max_new_tokens=10, suppress_eos=True).tokens
+    r2 = rt.generate(p, speech, max_new_tokens=10, suppress_eos=True).tokens
+    assert r1.shape == (1, 10) and torch.equal(r1, r2)
+    assert int(r1.min()) >= 0 and int(r1.max()) < 32001
+
+
+def test_logmel_of_silence_is_the_closed_form_constant(rt):
+    # all-zero audio: power 0 -> log10(1e-10) = -10 everywhere -> max-8 clamp keeps -10 -> (x+4)/4 = -1.5
+    spec = rt.log_mel(torch.zeros(1, 480000), [480000])
+    assert torch.all(spec == -1.5)
