@@ -116,8 +116,72 @@ class SalmonProcessor:
         return batch
 
 
+class QwenProcessor:
+    """Mirror of the reference's ``QwenProcessor`` for the classification tasks (data/model_processors.py:153-223 inputs,
+    :318-383 chat-template prompt, :428-472 collate).  ``processor`` is ``CustomQwen.input_processor``: its ``__call__``
+    computes the 128-bin log-mel on the GPU, so build the DataLoader with ``num_workers=0`` for this model type (the
+    reference's AutoProcessor runs the feature extractor on CPU workers)."""
+
+    def __init__(self, processor, max_length: int = 512):
+        self.processor = processor
+        self.max_length = max_length
+
+    def format_prompt(self, template: str, text: str, examples: Optional[List[Dict]] = None,
+                      input_mode: str = "speech_only", fewshot_mode: str = "text", dataset_type=None, **kw) -> str:
+        user: List[Dict[str, Any]] = []
+        if examples:
+            user.append({"type": "text", "text": "Here are few examples to learn from:\n"})
+            for ex in examples:
+                if fewshot_mode == "speech":
+                    user += [{"type": "audio", "audio_url": "dummy_url"}, {"type": "text", "text": f"Label: {ex.get('label', '')}\n"}]
+                else:
+                    user += [{"type": "text", "text": f"Text: {ex.get('text', '')}\n"},
+                             {"type": "text", "text": f"Label: {ex.get('label', '')}\n"}]
+        user.append({"type": "text", "text": "\nNow analyze this input:\n"})
+        if input_mode in ("speech_only", "speech_and_text"):
+            user.append({"type": "audio", "audio_url": "dummy_url"})
+        if input_mode == "speech_and_text" and text:
+            user.append({"type": "text", "text": text})
+        conv = [{"role": "system", "content": template}, {"role": "user", "content": user}]
+        return self.processor.apply_chat_template(conv, add_generation_prompt=True, tokenize=False)
+
+    def process_inputs(self, data: Dict[str, Any], is_training: bool = False) -> Dict[str, Any]:
+        text = data.get("prompt", "")
+        audios = list(data.get("examples_audio") or [])
+        if data.get("audio") is not None:
+            audios.append(data["audio"])
+        full = text + (f"{data.get('completion', '')}{self.processor.tokenizer.eos_token}" if is_training else "")
+        prompt_len = self.processor(text=text, audios=audios, return_tensors="pt", sampling_rate=16000).input_ids.shape[1]
+        enc = self.processor(text=full, audios=audios, return_tensors="pt", sampling_rate=16000)
+        out = {"input_ids": enc.input_ids.squeeze(0), "attention_mask": enc.attention_mask.squeeze(0), "prompt_length": prompt_len}
+        if audios:
+            out["input_features"] = enc.input_features
+            out["feature_attention_mask"] = enc.feature_attention_mask
+        return out
+
+    def collate_batch(self, items: List[Dict[str, Any]]) -> Dict[str, Any]:
+        S = max(it["input_ids"].numel() for it in items)
+        pad = getattr(self.processor.tokenizer, "pad_token_id", 0) or 0
+        ids = torch.full((len(items), S), pad, dtype=torch.long)
+        att = torch.zeros(len(items), S, dtype=torch.long)
+        for i, it in enumerate(items):     # right padding; the model strips it through attention_mask
+            n = it["input_ids"].numel()
+            ids[i, :n], att[i, :n] = it["input_ids"], it["attention_mask"]
+        batch: Dict[str, Any] = {"input_ids": ids, "attention_mask": att,
+                                 "prompt_length": torch.tensor([it["prompt_length"] for it in items])}
+        if all("input_features" in it for it in items):
+            batch["input_features"] = torch.cat([it["input_features"] for it in items])
+            batch["feature_attention_mask"] = torch.cat([it["feature_attention_mask"] for it in items])
+        for key in ("prompt", "completion", "text", "dataset_type"):
+            if key in items[0]:
+                batch[key] = [it[key] for it in items]
+        return batch
+
+
 def get_processor(model_type: str, processor=None, tokenizer=None, **kw):
     """Reference: data/model_processors.get_processor (:1012-1030)."""
     if model_type == "salmonn":
         return SalmonProcessor(tokenizer, feature_extractor=processor, **kw)
+    if model_type == "qwen2":
+        return QwenProcessor(processor, **kw)
     raise ValueError(f"Unsupported model type for the MI355X path: {model_type}")

@@ -110,7 +110,11 @@ def run_inference(args) -> Dict[str, Any]:
         else:
             logger.info("No checkpoint path provided, using base model without loading weights")
         model.to(args.device)
-        processor = get_processor(args.model_type, model.input_processor, model.llama_tokenizer)
+        if args.model_type == "salmonn":
+            processor = get_processor(args.model_type, model.input_processor, model.llama_tokenizer)
+        else:   # the Qwen host processor computes its log-mel on the GPU: keep item processing in the main process
+            processor = get_processor(args.model_type, model.input_processor)
+            args.num_workers = 0
         if args.dataset_root:
             raise NotImplementedError("real-dataset loading (SURVEY.md §8 f2) is not implemented; omit --dataset_root")
         n_items = args.debug_samples if args.debug_samples and args.debug_samples > 0 else args.synthetic_items

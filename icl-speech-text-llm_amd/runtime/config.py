@@ -68,6 +68,8 @@ class LlamaCfg:
     pad_id: int = 32000
     lora_rank: int = 8        # 0 = no LoRA
     lora_alpha: float = 32.0  # config/inference_config.py:36 (class default is 16, custom_salmon.py:45)
+    lora_targets: tuple = ("q_proj", "v_proj")   # peft's Llama default (SALMONN); Qwen path: ("q_proj", "k_proj"), custom_qwen.py:75
+    qkv_bias: bool = False    # Qwen2 attention has q/k/v biases
 
     @property
     def head_dim(self) -> int:
@@ -108,6 +110,25 @@ class SalmonnCfg:
         l = LlamaCfg(hidden=256, n_layers=2, n_heads=2, ffn=512, vocab=vocab, max_pos=2048, pad_id=vocab - 1,
                      lora_rank=8 if lora else 0)
         return SalmonnCfg(whisper=w, beats=b, qformer=q, llama=l)
+
+
+@dataclass(frozen=True)
+class QwenAudioCfg:
+    """Qwen2-Audio (models/custom_qwen.py:51-55): Whisper-style 128-mel audio tower + AvgPool(2) + ln_post, a
+    Linear projector and a Qwen2 decoder.  LM dims follow the Qwen2-Audio-7B-Instruct checkpoint (hidden 4096, 32 layers,
+    32 heads, FFN 11008, vocab 156032) [upstream config.json — to be confirmed when the checkpoint is reachable]."""
+    audio: WhisperCfg = field(default_factory=lambda: WhisperCfg(n_mels=128))
+    llm: LlamaCfg = field(default_factory=lambda: LlamaCfg(vocab=156032, rms_eps=1e-5, rope_theta=10000.0, max_pos=8192,
+                                                           bos_id=151643, eos_id=151645, pad_id=151643, qkv_bias=True,
+                                                           lora_targets=("q_proj", "k_proj")))
+    audio_token_id: int = 151646
+
+    @staticmethod
+    def tiny(lora: bool = True, vocab: int = 300) -> "QwenAudioCfg":
+        a = WhisperCfg(d_model=128, n_layers=2, n_heads=2, ffn=256, n_mels=128)
+        l = LlamaCfg(hidden=256, n_layers=2, n_heads=2, ffn=512, vocab=vocab, max_pos=4096, bos_id=1, eos_id=2,
+                     pad_id=vocab - 1, lora_rank=8 if lora else 0, qkv_bias=True, lora_targets=("q_proj", "k_proj"))
+        return QwenAudioCfg(audio=a, llm=l, audio_token_id=vocab - 2)
 
 
 def with_llama(cfg: SalmonnCfg, **kw) -> SalmonnCfg:

@@ -77,8 +77,10 @@ class WhisperEncoderHIP:
     def __init__(self, w: PackedWhisper):
         self.w = w
 
-    def forward(self, ws: Workspace, xt: torch.Tensor) -> torch.Tensor:
-        """xt bf16 [n, 3002, 128] -> final-LayerNorm output f32 [n*1500, d]."""
+    def forward(self, ws: Workspace, xt: torch.Tensor, kv_lens: Optional[torch.Tensor] = None,
+                final_ln: bool = True) -> torch.Tensor:
+        """xt bf16 [n, 3002, 128] -> final-LayerNorm output f32 [n*1500, d] (or the pre-LN stream if not final_ln).
+        kv_lens (device int32 [n]): key padding length per audio (Qwen2-Audio masks encoder frames past the audio)."""
         w, c = self.w, self.w.cfg
         n, d, T = xt.shape[0], c.d_model, c.n_ctx
         M = n * T
@@ -101,13 +103,49 @@ class WhisperEncoderHIP:
         for L in w.layers:
             B.layernorm(h, L.ln1_g, L.ln1_b, xn, 1e-5)
             B.gemm(xn, L.wqkv, qkv, bias=L.bqkv)
-            B.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, cu, T, c.n_heads, D, D ** -0.5)
+            B.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, cu, T, c.n_heads, D, D ** -0.5, kv_lens=kv_lens)
             B.gemm(att, L.wo, h, bias=L.bo, residual=h)
             B.layernorm(h, L.ln2_g, L.ln2_b, xn, 1e-5)
             B.gemm(xn, L.w1, ff, bias=L.b1, gelu=True)
             B.gemm(ff, L.w2, h, bias=L.b2, residual=h)
+        if not final_ln:
+            return h
         B.layernorm(h, w.lnf_g, w.lnf_b, out, 1e-5)
         return out
+
+
+# ================================================================================================
+# K13: Qwen2-Audio tower = Whisper-style encoder (128 mel, key padding) -> AvgPool1d(2,2) -> ln_post -> projector
+# ================================================================================================
+class QwenAudioTowerHIP:
+    """HF Qwen2AudioEncoder + Qwen2AudioMultiModalProjector (modeling_qwen2_audio.py:289-421), reached from the
+    reference at models/custom_qwen.py:188-195 / :228-234."""
+
+    def __init__(self, enc: WhisperEncoderHIP, proj_w: torch.Tensor, proj_b: torch.Tensor, llm_hidden: int):
+        self.enc, self.proj_w, self.proj_b, self.llm_hidden = enc, proj_w, proj_b, llm_hidden
+
+    @staticmethod
+    def output_lengths(mel_len: int):
+        feat = (mel_len - 1) // 2 + 1          # after the stride-2 conv
+        return feat, (feat - 2) // 2 + 1       # after AvgPool1d(2, 2)
+
+    def forward(self, ws: Workspace, xt: torch.Tensor, mel_lens: List[int]) -> Tuple[torch.Tensor, List[int]]:
+        """xt bf16 [n, 3002, 128], mel_lens (valid mel frames per audio) -> (features f32 [n*750, H_llm], valid rows per audio)."""
+        w, c = self.enc.w, self.enc.w.cfg
+        n, d, T = xt.shape[0], c.d_model, c.n_ctx
+        lens = [self.output_lengths(int(m)) for m in mel_lens]
+        kv = _i32([max(1, f) for f, _ in lens], xt.device)
+        h = self.enc.forward(ws, xt, kv_lens=kv, final_ln=False)                 # [n*1500, d] f32
+        P = n * (T // 2)
+        pooled = ws.get("qa_pool", (P, d), F32)
+        even, odd = h.view(P, 2 * d)[:, :d], h.view(P, 2 * d)[:, d:]           # frames 2t / 2t+1 as strided row views
+        B.axpby_cast(odd, pooled, alpha=0.5)
+        B.axpby_cast(even, pooled, alpha=0.5, add=pooled)
+        pb = ws.get("qa_pool_bf", (P, d), BF16)
+        B.layernorm(pooled, w.lnf_g, w.lnf_b, pb, 1e-5)
+        out = ws.get("qa_out", (P, self.llm_hidden), F32)
+        B.gemm(pb, self.proj_w, out, bias=self.proj_b)
+        return out, [o for _, o in lens]
 
 
 # ================================================================================================
@@ -301,10 +339,10 @@ class LlamaHIP:
         B.rmsnorm(h, L.rms1, xn, c.rms_eps, N=hd)
         if L.lora_a is not None:   # x_aug[:, hd:hd+2r] = x @ (s*A)^T : a skinny GEMM for prefill, a GEMV-style kernel for decode
             if split is None:   # prefill (any M: the choice must not depend on the batch, or rows would not be batch-invariant)
-                B.gemm(xn, L.lora_a, xn[:, hd:hd + 2 * c.lora_rank], K=hd, tile=2)
+                B.gemm(xn, L.lora_a, xn[:, hd:hd + L.lora_a.shape[0]], K=hd, tile=2)
             else:               # decode
-                B.lora_down(xn, hd, L.lora_a, 2 * c.lora_rank, 1.0, M=M)
-        B.gemm(xn, L.wqkv, qkv, split_k=sk.get("qkv", 1), workspace=wsk, tile=sk.get("tile", 0))
+                B.lora_down(xn, hd, L.lora_a, L.lora_a.shape[0], 1.0, M=M)
+        B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1), workspace=wsk, tile=sk.get("tile", 0))
         B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
         attn_fn(qkv, att)
         B.gemm(att, L.wo, h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=sk.get("tile", 0))

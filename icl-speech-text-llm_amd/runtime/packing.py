@@ -256,6 +256,7 @@ def pack_qformer(sd: SD, cfg: QFormerCfg, device, consume: bool = False) -> Pack
 @dataclass
 class LlamaLayer:
     rms1: torch.Tensor
+    bqkv: Optional[torch.Tensor]  # f32 [3h] (Qwen2) or None
     wqkv: torch.Tensor           # [3h, K_aug]
     lora_a: Optional[torch.Tensor]  # [2r, h], pre-multiplied by alpha/r
     wo: torch.Tensor
@@ -277,11 +278,12 @@ class PackedLlama:
 
 
 def pack_llama(sd: SD, cfg: LlamaCfg, device, prefix: str = "llama_model.", consume: bool = False) -> PackedLlama:
+    """HF causal-LM names under `prefix`: model.embed_tokens, model.layers.{i}.*, model.norm, lm_head (Llama and Qwen2 alike)."""
     h, I, r = cfg.hidden, cfg.ffn, cfg.lora_rank
     assert h % 64 == 0 and I % 64 == 0 and cfg.head_dim in (64, 128)
     p = prefix + "model."
     k_aug = h + (LORA_PAD if r else 0)
-    assert 2 * r <= LORA_PAD
+    assert len(cfg.lora_targets) * r <= LORA_PAD and all(t in ("q_proj", "k_proj", "v_proj") for t in cfg.lora_targets)
     layers = []
     for i in range(cfg.n_layers):
         lp = f"{p}layers.{i}."
@@ -289,19 +291,24 @@ def pack_llama(sd: SD, cfg: LlamaCfg, device, prefix: str = "llama_model.", cons
         for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
             wqkv[j * h:(j + 1) * h, :h] = _take(sd, lp + f"self_attn.{n}.weight", consume).to(device=device, dtype=torch.bfloat16)
         lora_a = None
-        if r:
-            aq, av = _take(sd, lp + "self_attn.q_proj.lora_A.weight", consume), _take(sd, lp + "self_attn.v_proj.lora_A.weight", consume)
-            bq, bv = _take(sd, lp + "self_attn.q_proj.lora_B.weight", consume), _take(sd, lp + "self_attn.v_proj.lora_B.weight", consume)
-            wqkv[0:h, h:h + r] = bq.to(device=device, dtype=torch.bfloat16)
-            wqkv[2 * h:3 * h, h + r:h + 2 * r] = bv.to(device=device, dtype=torch.bfloat16)
+        if r:   # K-augmentation: target t (one of q/k/v) gets its B in column block [h + i*r, h + (i+1)*r) of its own rows
+            a_rows = []
+            for i, tgt in enumerate(cfg.lora_targets):
+                j = ("q_proj", "k_proj", "v_proj").index(tgt)
+                a_rows.append(_take(sd, lp + f"self_attn.{tgt}.lora_A.weight", consume))
+                wqkv[j * h:(j + 1) * h, h + i * r:h + (i + 1) * r] = \
+                    _take(sd, lp + f"self_attn.{tgt}.lora_B.weight", consume).to(device=device, dtype=torch.bfloat16)
             # the LoRA scale (alpha/r) is folded into A here so the down-projection can run as a plain GEMM
-            lora_a = _bf(torch.cat([aq, av], 0).float() * cfg.lora_scale, device)
+            lora_a = _bf(torch.cat(a_rows, 0).float() * cfg.lora_scale, device)
+        bqkv = None
+        if cfg.qkv_bias:
+            bqkv = _f32(torch.cat([_take(sd, lp + f"self_attn.{n}.bias", consume).float() for n in ("q_proj", "k_proj", "v_proj")]), device)
         g = _take(sd, lp + "mlp.gate_proj.weight", consume).to(device=device, dtype=torch.bfloat16)
         u = _take(sd, lp + "mlp.up_proj.weight", consume).to(device=device, dtype=torch.bfloat16)
         wgu = torch.stack([g.view(I // 16, 16, h), u.view(I // 16, 16, h)], dim=1).reshape(2 * I, h).contiguous()
         del g, u
         layers.append(LlamaLayer(
-            rms1=_f32(_take(sd, lp + "input_layernorm.weight", consume), device), wqkv=wqkv, lora_a=lora_a,
+            rms1=_f32(_take(sd, lp + "input_layernorm.weight", consume), device), bqkv=bqkv, wqkv=wqkv, lora_a=lora_a,
             wo=_bf(_take(sd, lp + "self_attn.o_proj.weight", consume), device),
             rms2=_f32(_take(sd, lp + "post_attention_layernorm.weight", consume), device), wgu=wgu,
             wdown=_bf(_take(sd, lp + "mlp.down_proj.weight", consume), device)))

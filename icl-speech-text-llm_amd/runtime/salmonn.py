@@ -32,13 +32,132 @@ class GenerateResult:
     first_logits: Optional[torch.Tensor] = None  # f32 [B, V] (device) logits of the first generated position
 
 
-class SalmonnRuntime:
+class CausalLMRuntimeMixin:
+    """K9-K12 over a packed decoder (`self.llama`: LlamaHIP, `self.lm_cfg`: LlamaCfg, `self.ws`, `self.device`):
+    prompt segments -> gather/interleave -> prefill -> greedy decode / teacher-forced logits.  Shared by the SALMONN
+    (Llama-2 / Vicuna) and Qwen2-Audio runtimes."""
+
+    # --------------------------------------------------------------------------------------------
+    # K9: prompt segments -> gather indices
+    # --------------------------------------------------------------------------------------------
+    def _gather_indices(self, prompts: Sequence[Sequence[Segment]], n_speech_rows: int) -> Tuple[List[int], List[int]]:
+        V = self.lm_cfg.vocab
+        flat: List[int] = []
+        lens: List[int] = []
+        for segs in prompts:
+            before = len(flat)
+            for seg in segs:
+                if isinstance(seg, tuple) and len(seg) == 3 and seg[0] == "speech":
+                    _, first, cnt = seg
+                    if first < 0 or first + cnt > n_speech_rows:
+                        raise ValueError(f"speech segment [{first},{first + cnt}) outside {n_speech_rows} speech rows")
+                    flat.extend(-(r + 1) for r in range(first, first + cnt))
+                else:
+                    for t in seg:
+                        t = int(t)
+                        if not 0 <= t < V:
+                            raise ValueError(f"token id {t} outside the vocabulary [0,{V})")
+                        flat.append(t)
+            if len(flat) == before:
+                raise ValueError("empty prompt")
+            lens.append(len(flat) - before)
+        return flat, lens
+
+    def embed_prompts(self, prompts, speech: Optional[torch.Tensor], name: str = "ll_h"):
+        rows = 0 if speech is None else speech.shape[0] * (speech.shape[1] if speech.dim() == 3 else 1)
+        sp2 = None if speech is None else speech.reshape(rows, self.lm_cfg.hidden).contiguous()
+        flat, lens = self._gather_indices(prompts, rows)
+        h = self.llama.embed(self.ws, _i32(flat, self.device), sp2, name=name)
+        return h, lens
+
+    # --------------------------------------------------------------------------------------------
+    # K10 (+K12): teacher-forced forward
+    # --------------------------------------------------------------------------------------------
+    def forward_logits(self, prompts, speech: Optional[torch.Tensor]) -> Tuple[torch.Tensor, List[int]]:
+        """All-position logits f32 [sum S_b, V] (packed) and the per-sequence lengths."""
+        h, lens = self.embed_prompts(prompts, speech, name="fw_h")
+        self.llama.prefill(self.ws, h, lens, cache=None)
+        return self.llama.logits(self.ws, h, name="fw_logits"), lens
+
+    def cross_entropy(self, logits: torch.Tensor, shifted_labels: torch.Tensor) -> torch.Tensor:
+        """mean CE over rows with label >= 0; logits f32 [M, V] (device), shifted_labels int32 [M]."""
+        M = logits.shape[0]
+        rows = self.ws.get("ce_rows", (M,), F32)
+        mean = self.ws.get("ce_mean", (1,), F32)
+        B.cross_entropy(logits, shifted_labels.to(device=self.device, dtype=I32), rows, mean)
+        return mean
+
+    # --------------------------------------------------------------------------------------------
+    # K10 + K11: greedy generate
+    # --------------------------------------------------------------------------------------------
+    def _cache(self, n_seqs: int, max_len: int) -> KVCache:
+        key = (n_seqs, max_len)
+        c = self._caches.get(key)
+        if c is None:
+            if len(self._caches) > 4:
+                self._caches.clear()
+            c = self._caches[key] = KVCache(self.lm_cfg, n_seqs, max_len, self.device)
+        return c
+
+    def generate(self, prompts, speech: Optional[torch.Tensor], max_new_tokens: int = 10, eos_id: Optional[int] = None,
+                 pad_id: Optional[int] = None, suppress_eos: bool = False, want_first_logits: bool = False,
+                 cache_len_multiple: int = 64) -> GenerateResult:
+        """Greedy search with HF ``generate(inputs_embeds=…)`` semantics (models/custom_salmon.py:704-720): returns only
+        the new tokens; a row that has emitted EOS is filled with pad; the width is that of the longest row
+        (``min_length`` is a no-op with inputs_embeds, SURVEY.md A6).  All steps are enqueued without a host sync; the
+        early-stop width is applied on the host afterwards (identical output, no per-token round trip)."""
+        c, ws, dev = self.lm_cfg, self.ws, self.device
+        eos = c.eos_id if eos_id is None else eos_id
+        pad = c.pad_id if pad_id is None else pad_id
+        if suppress_eos:
+            eos = -1  # benchmark mode (SURVEY.md §8d): exactly max_new_tokens per row
+        assert max_new_tokens >= 1
+        h, lens = self.embed_prompts(prompts, speech)
+        Bn = len(lens)
+        need = max(lens) + max_new_tokens
+        max_len = -(-need // cache_len_multiple) * cache_len_multiple
+        assert max_len <= c.max_pos, f"prompt + new tokens ({need}) exceeds max_pos {c.max_pos}"
+        cache = self._cache(Bn, max_len)
+        self.llama.prefill(ws, h, lens, cache)
+        cu_last = []
+        acc = 0
+        for s in lens:
+            acc += s
+            cu_last.append(acc - 1)
+        last = ws.get("gen_last", (Bn, c.hidden), F32)
+        B.gather_rows(h, _i32(cu_last, dev), last)
+        logits = self.llama.logits(ws, last, name="gen_logits")
+        first = logits.clone() if want_first_logits else None
+        finished = ws.get("gen_finished", (Bn,), I32)
+        finished.zero_()
+        toks = ws.get("gen_tokens", (Bn, max_new_tokens), I32)
+        nxt = ws.get("gen_next", (Bn,), I32)
+        B.argmax_eos(logits, eos, pad, finished, toks, 0, nxt)
+        if max_new_tokens > 1:
+            steps = max_new_tokens - 1
+            pos_all = _i32([[s + t for s in lens] for t in range(steps)], dev)          # position of the fed token
+            len_all = _i32([[s + t + 1 for s in lens] for t in range(steps)], dev)      # cache length after append
+            sid = _i32(list(range(Bn)), dev)
+            for t in range(steps):
+                lg = self.llama.decode_step(ws, cache, nxt, pos_all[t], len_all[t], sid)
+                B.argmax_eos(lg, eos, pad, finished, toks, t + 1, nxt)
+        out = toks.cpu().to(torch.int64)                                                 # the only D2H of the call
+        width = max_new_tokens
+        if eos >= 0:
+            is_eos = out == eos
+            first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((Bn,), max_new_tokens))
+            width = int(first_eos.max())
+        return GenerateResult(tokens=out[:, :width].contiguous(), first_logits=first)
+
+
+class SalmonnRuntime(CausalLMRuntimeMixin):
     def __init__(self, cfg: SalmonnCfg, state_dict: Dict[str, torch.Tensor], device="cuda", consume: bool = False,
                  parts: Sequence[str] = ("whisper", "beats", "qformer", "llama")):
         if not torch.cuda.is_available():
             raise B.IclError("SalmonnRuntime needs a GPU: the HIP path has no CPU fallback")
         B.load_library()
         self.cfg = cfg
+        self.lm_cfg = cfg.llama
         self.device = torch.device(device)
         sd = normalize_keys(state_dict) if not consume else state_dict
         self.ws = Workspace(self.device)
@@ -99,114 +218,3 @@ class SalmonnRuntime:
         _, spec = self.logmel(self.ws, raw_wav, _i32([int(x) for x in wav_lens], self.device), want_spec=True)
         return spec
 
-    # --------------------------------------------------------------------------------------------
-    # K9: prompt segments -> gather indices
-    # --------------------------------------------------------------------------------------------
-    def _gather_indices(self, prompts: Sequence[Sequence[Segment]], n_speech_rows: int) -> Tuple[List[int], List[int]]:
-        V = self.cfg.llama.vocab
-        flat: List[int] = []
-        lens: List[int] = []
-        for segs in prompts:
-            before = len(flat)
-            for seg in segs:
-                if isinstance(seg, tuple) and len(seg) == 3 and seg[0] == "speech":
-                    _, first, cnt = seg
-                    if first < 0 or first + cnt > n_speech_rows:
-                        raise ValueError(f"speech segment [{first},{first + cnt}) outside {n_speech_rows} speech rows")
-                    flat.extend(-(r + 1) for r in range(first, first + cnt))
-                else:
-                    for t in seg:
-                        t = int(t)
-                        if not 0 <= t < V:
-                            raise ValueError(f"token id {t} outside the vocabulary [0,{V})")
-                        flat.append(t)
-            if len(flat) == before:
-                raise ValueError("empty prompt")
-            lens.append(len(flat) - before)
-        return flat, lens
-
-    def embed_prompts(self, prompts, speech: Optional[torch.Tensor], name: str = "ll_h"):
-        rows = 0 if speech is None else speech.shape[0] * (speech.shape[1] if speech.dim() == 3 else 1)
-        sp2 = None if speech is None else speech.reshape(rows, self.cfg.llama.hidden).contiguous()
-        flat, lens = self._gather_indices(prompts, rows)
-        h = self.llama.embed(self.ws, _i32(flat, self.device), sp2, name=name)
-        return h, lens
-
-    # --------------------------------------------------------------------------------------------
-    # K10 (+K12): teacher-forced forward
-    # --------------------------------------------------------------------------------------------
-    def forward_logits(self, prompts, speech: Optional[torch.Tensor]) -> Tuple[torch.Tensor, List[int]]:
-        """All-position logits f32 [sum S_b, V] (packed) and the per-sequence lengths."""
-        h, lens = self.embed_prompts(prompts, speech, name="fw_h")
-        self.llama.prefill(self.ws, h, lens, cache=None)
-        return self.llama.logits(self.ws, h, name="fw_logits"), lens
-
-    def cross_entropy(self, logits: torch.Tensor, shifted_labels: torch.Tensor) -> torch.Tensor:
-        """mean CE over rows with label >= 0; logits f32 [M, V] (device), shifted_labels int32 [M]."""
-        M = logits.shape[0]
-        rows = self.ws.get("ce_rows", (M,), F32)
-        mean = self.ws.get("ce_mean", (1,), F32)
-        B.cross_entropy(logits, shifted_labels.to(device=self.device, dtype=I32), rows, mean)
-        return mean
-
-    # --------------------------------------------------------------------------------------------
-    # K10 + K11: greedy generate
-    # --------------------------------------------------------------------------------------------
-    def _cache(self, n_seqs: int, max_len: int) -> KVCache:
-        key = (n_seqs, max_len)
-        c = self._caches.get(key)
-        if c is None:
-            if len(self._caches) > 4:
-                self._caches.clear()
-            c = self._caches[key] = KVCache(self.cfg.llama, n_seqs, max_len, self.device)
-        return c
-
-    def generate(self, prompts, speech: Optional[torch.Tensor], max_new_tokens: int = 10, eos_id: Optional[int] = None,
-                 pad_id: Optional[int] = None, suppress_eos: bool = False, want_first_logits: bool = False,
-                 cache_len_multiple: int = 64) -> GenerateResult:
-        """Greedy search with HF ``generate(inputs_embeds=…)`` semantics (models/custom_salmon.py:704-720): returns only
-        the new tokens; a row that has emitted EOS is filled with pad; the width is that of the longest row
-        (``min_length`` is a no-op with inputs_embeds, SURVEY.md A6).  All steps are enqueued without a host sync; the
-        early-stop width is applied on the host afterwards (identical output, no per-token round trip)."""
-        c, ws, dev = self.cfg.llama, self.ws, self.device
-        eos = c.eos_id if eos_id is None else eos_id
-        pad = c.pad_id if pad_id is None else pad_id
-        if suppress_eos:
-            eos = -1  # benchmark mode (SURVEY.md §8d): exactly max_new_tokens per row
-        assert max_new_tokens >= 1
-        h, lens = self.embed_prompts(prompts, speech)
-        Bn = len(lens)
-        need = max(lens) + max_new_tokens
-        max_len = -(-need // cache_len_multiple) * cache_len_multiple
-        assert max_len <= c.max_pos, f"prompt + new tokens ({need}) exceeds max_pos {c.max_pos}"
-        cache = self._cache(Bn, max_len)
-        self.llama.prefill(ws, h, lens, cache)
-        cu_last = []
-        acc = 0
-        for s in lens:
-            acc += s
-            cu_last.append(acc - 1)
-        last = ws.get("gen_last", (Bn, c.hidden), F32)
-        B.gather_rows(h, _i32(cu_last, dev), last)
-        logits = self.llama.logits(ws, last, name="gen_logits")
-        first = logits.clone() if want_first_logits else None
-        finished = ws.get("gen_finished", (Bn,), I32)
-        finished.zero_()
-        toks = ws.get("gen_tokens", (Bn, max_new_tokens), I32)
-        nxt = ws.get("gen_next", (Bn,), I32)
-        B.argmax_eos(logits, eos, pad, finished, toks, 0, nxt)
-        if max_new_tokens > 1:
-            steps = max_new_tokens - 1
-            pos_all = _i32([[s + t for s in lens] for t in range(steps)], dev)          # position of the fed token
-            len_all = _i32([[s + t + 1 for s in lens] for t in range(steps)], dev)      # cache length after append
-            sid = _i32(list(range(Bn)), dev)
-            for t in range(steps):
-                lg = self.llama.decode_step(ws, cache, nxt, pos_all[t], len_all[t], sid)
-                B.argmax_eos(lg, eos, pad, finished, toks, t + 1, nxt)
-        out = toks.cpu().to(torch.int64)                                                 # the only D2H of the call
-        width = max_new_tokens
-        if eos >= 0:
-            is_eos = out == eos
-            first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((Bn,), max_new_tokens))
-            width = int(first_eos.max())
-        return GenerateResult(tokens=out[:, :width].contiguous(), first_logits=first)

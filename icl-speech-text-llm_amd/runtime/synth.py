@@ -134,8 +134,11 @@ def llama_state(cfg: LlamaCfg, g: _Gen, prefix: str = "llama_model.") -> SD:
         lp = f"{p}layers.{i}."
         for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
             sd[lp + f"self_attn.{n}.weight"] = g.normal(h, h)
+        if cfg.qkv_bias:
+            for n in ("q_proj", "k_proj", "v_proj"):
+                sd[lp + f"self_attn.{n}.bias"] = g.bias(h) if g.jitter else 0.02 * torch.randn(h, generator=g.g, device=g.device)
         if cfg.lora_rank:
-            for n in ("q_proj", "v_proj"):
+            for n in cfg.lora_targets:
                 sd[lp + f"self_attn.{n}.lora_A.weight"] = g.normal(cfg.lora_rank, h)
                 sd[lp + f"self_attn.{n}.lora_B.weight"] = g.normal(h, cfg.lora_rank, std=0.01)
         sd[lp + "mlp.gate_proj.weight"] = g.normal(cfg.ffn, h)
@@ -162,4 +165,16 @@ def salmonn_state(cfg: SalmonnCfg, seed: int = 0, device="cpu", dtype=torch.floa
                                 cfg.beats.d_model if cfg.beats is not None else 0))
     if "llama" in parts:
         sd.update(llama_state(cfg.llama, g))
+    return sd
+
+
+def qwen_audio_state(cfg, seed: int = 0, device="cpu", dtype=torch.float32, jitter: bool = False) -> SD:
+    """Synthetic Qwen2-Audio checkpoint under HF Qwen2AudioForConditionalGeneration names: ``audio_tower.*``,
+    ``multi_modal_projector.linear.*``, ``language_model.model.*`` / ``language_model.lm_head.weight``."""
+    g = _Gen(seed, device, dtype, jitter)
+    sd: SD = {}
+    sd.update(whisper_state(cfg.audio, g, prefix="audio_tower."))
+    sd["multi_modal_projector.linear.weight"] = g.normal(cfg.llm.hidden, cfg.audio.d_model)
+    sd["multi_modal_projector.linear.bias"] = g.bias(cfg.llm.hidden)
+    sd.update(llama_state(cfg.llm, g, prefix="language_model."))
     return sd

@@ -78,7 +78,7 @@ def _mha(q: Tensor, k: Tensor, v: Tensor, n_heads: int, scale: float, mask: Opti
 # K2 + K3: Whisper encoder (HF WhisperEncoder semantics)
 # ---------------------------------------------------------------------------------------------
 def whisper_encoder(sd: SD, spec: Tensor, n_heads: int, prefix: str = "", rnd: Optional[Callable] = None,
-                    return_layers: bool = False):
+                    return_layers: bool = False, key_lens: Optional[List[int]] = None, final_ln: bool = True):
     """spec f32 [B, n_mel, 3000] -> [B, 1500, d].  Keys: conv1/conv2, embed_positions.weight,
     layers.{i}.{self_attn.{q,k,v,out}_proj, self_attn_layer_norm, fc1, fc2, final_layer_norm}, layer_norm."""
     rnd = rnd or _id
@@ -92,21 +92,45 @@ def whisper_encoder(sd: SD, spec: Tensor, n_heads: int, prefix: str = "", rnd: O
     scale = (d // n_heads) ** -0.5
     n_layers = 1 + max(int(k[len(p):].split(".")[1]) for k in sd if k.startswith(p + "layers."))
     layers = []
+    kmask = None
+    if key_lens is not None:   # Qwen2-Audio: encoder frames past the audio are masked as keys
+        kmask = (torch.arange(h.shape[1])[None, :] >= torch.tensor(key_lens)[:, None])[:, None, None, :]
     for i in range(n_layers):
         lp = f"{p}layers.{i}."
         xn = _ln(h, sd, lp + "self_attn_layer_norm", 1e-5)
         q = rnd(_lin(xn, sd, lp + "self_attn.q_proj", rnd))
         k = rnd(_lin(xn, sd, lp + "self_attn.k_proj", rnd))
         v = rnd(_lin(xn, sd, lp + "self_attn.v_proj", rnd))
-        a = rnd(_mha(q, k, v, n_heads, scale))
+        a = rnd(_mha(q, k, v, n_heads, scale, mask=kmask))
         h = h + _lin(a, sd, lp + "self_attn.out_proj", rnd)
         xn = _ln(h, sd, lp + "final_layer_norm", 1e-5)
         f = rnd(F.gelu(_lin(xn, sd, lp + "fc1", rnd)))
         h = h + _lin(f, sd, lp + "fc2", rnd)
         if return_layers:
             layers.append(h.clone())
+    if not final_ln:
+        return h
     out = _ln(h, sd, p + "layer_norm", 1e-5)
     return (out, layers) if return_layers else out
+
+
+# ---------------------------------------------------------------------------------------------
+# K13: Qwen2-Audio tower + projector (HF Qwen2AudioEncoder / Qwen2AudioMultiModalProjector semantics)
+# ---------------------------------------------------------------------------------------------
+def qwen_audio_lengths(mel_len: int) -> Tuple[int, int]:
+    feat = (mel_len - 1) // 2 + 1
+    return feat, (feat - 2) // 2 + 1
+
+
+def qwen_audio_features(sd: SD, spec: Tensor, mel_lens: List[int], n_heads: int, rnd: Optional[Callable] = None):
+    """spec f32 [n, 128, 3000] -> (projected features [n, 750, H_llm], valid rows per audio).  Keys: ``audio_tower.*``,
+    ``multi_modal_projector.linear.*``.  Reference call: models/custom_qwen.py:186-195 -> HF Qwen2AudioModel.forward."""
+    rnd = rnd or _id
+    lens = [qwen_audio_lengths(int(m)) for m in mel_lens]
+    h = whisper_encoder(sd, spec, n_heads, prefix="audio_tower.", rnd=rnd, key_lens=[f for f, _ in lens], final_ln=False)
+    pooled = F.avg_pool1d(h.transpose(1, 2), 2, 2).transpose(1, 2)
+    x = _ln(pooled, sd, "audio_tower.layer_norm", 1e-5)
+    return _lin(x, sd, "multi_modal_projector.linear", rnd), [o for _, o in lens]
 
 
 # ---------------------------------------------------------------------------------------------

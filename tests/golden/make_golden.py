@@ -206,6 +206,42 @@ def g5_reference_glue():
         json.dump(fmt, f, indent=1)
 
 
+def g7_qwen2_audio():
+    """HF Qwen2AudioForConditionalGeneration (tiny dims, seeded weights): audio tower + masked scatter + Qwen2 LM."""
+    from transformers import Qwen2AudioConfig, Qwen2AudioEncoderConfig, Qwen2AudioForConditionalGeneration, Qwen2Config
+    torch.manual_seed(7)
+    acfg = Qwen2AudioEncoderConfig(num_mel_bins=128, d_model=32, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=64,
+                                   max_source_positions=1500)
+    tcfg = Qwen2Config(vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                       num_key_value_heads=2, rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=4096,
+                       tie_word_embeddings=False)
+    cfg = Qwen2AudioConfig(audio_config=acfg, text_config=tcfg, audio_token_index=298)
+    m = Qwen2AudioForConditionalGeneration(cfg).eval()
+    with torch.no_grad():
+        from icl_speech_text_llm_amd.runtime.synth import whisper_sinusoids
+        for n, p in m.named_parameters():
+            if "embed_positions" in n:      # a plain loaded table in Qwen2AudioEncoder: set it to the closed form so the
+                p.copy_(whisper_sinusoids(1500, 32))   # fixture need not store 1500x32 floats
+                continue
+            p.copy_(torch.randn_like(p) * (0.2 if p.dim() > 1 else 0.2) + (1.0 if ("norm" in n and n.endswith("weight")) else 0.0))
+        c, t = torch.arange(128.0)[:, None], torch.arange(3000.0)[None, :]
+        feats = torch.stack([0.5 * torch.sin(0.01 * (c + 1.0) * t + c), 0.4 * torch.cos(0.013 * (c + 2.0) * t)])
+        mel_lens = [3000, 1234]
+        fmask = torch.zeros(2, 3000, dtype=torch.long)
+        for i, L in enumerate(mel_lens):
+            fmask[i, :L] = 1
+        outl = [((L - 1) // 2 + 1 - 2) // 2 + 1 for L in mel_lens]
+        g = torch.Generator().manual_seed(8)
+        txt = lambda k: torch.randint(3, 290, (k,), generator=g).tolist()
+        ids = txt(10) + [298] * outl[0] + txt(5) + [298] * outl[1] + txt(6)
+        input_ids = torch.tensor([ids])
+        out = m(input_ids=input_ids, attention_mask=torch.ones_like(input_ids), input_features=feats, feature_attention_mask=fmask)
+        logits = out.logits[0]
+    sd = {k: v for k, v in m.state_dict().items() if "embed_positions" not in k}
+    save("qwen2_audio_tiny.npz", input_ids=input_ids[0], mel_lens=mel_lens, logits_tail=logits[-24:], logits_strided=logits[::97],
+         **{"w:" + k: v for k, v in sd.items()})
+
+
 def g8_clean_prediction():
     sys.path.insert(0, REF)
     from utils.evaluation_utils import clean_prediction as ref_clean
@@ -229,4 +265,5 @@ if __name__ == "__main__":
     g3_qformer()
     g4_llama()
     g5_reference_glue()
+    g7_qwen2_audio()
     g8_clean_prediction()

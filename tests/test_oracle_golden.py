@@ -108,6 +108,31 @@ def test_prompt_wrap_labels_logits_generate_match_reference_glue(case):
     assert tok.batch_decode(ids, skip_special_tokens=True)[0] == meta["generated_text"]
 
 
+def test_qwen2_audio_matches_hf():
+    """Oracle audio tower (key padding, AvgPool, ln_post, projector) + scatter + Qwen2 LM (QKV bias) vs HF
+    Qwen2AudioForConditionalGeneration on a 2-audio prompt."""
+    from icl_speech_text_llm_amd.runtime.qwen import normalize_qwen_keys
+    from icl_speech_text_llm_amd.runtime.synth import whisper_sinusoids
+    from oracle import models as om
+    a, sd = _load("qwen2_audio_tiny.npz")
+    sd = normalize_qwen_keys(sd)
+    sd["audio_tower.embed_positions.weight"] = whisper_sinusoids(1500, 32)
+    c, t = torch.arange(128.0)[:, None], torch.arange(3000.0)[None, :]
+    feats = torch.stack([0.5 * torch.sin(0.01 * (c + 1.0) * t + c), 0.4 * torch.cos(0.013 * (c + 2.0) * t)])
+    mel_lens = a["mel_lens"].tolist()
+    af, out_lens = om.qwen_audio_features(sd, feats, mel_lens, n_heads=2)
+    assert out_lens == [750, 308]
+    lsd = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}
+    llm = om.LlamaOracle(lsd, n_heads=2, rms_eps=1e-5)
+    ids = torch.from_numpy(a["input_ids"])
+    emb = llm.embed(ids)
+    pos = (ids == 298).nonzero().flatten()
+    emb[pos] = torch.cat([af[0, :750], af[1, :308]])
+    logits, _ = llm.forward(emb[None])
+    assert np.abs(logits[0, -24:].numpy() - a["logits_tail"]).max() < 5e-4
+    assert np.abs(logits[0, ::97].numpy() - a["logits_strided"]).max() < 5e-4
+
+
 def test_format_prompt_matches_reference_formatter():
     from icl_speech_text_llm_amd.data.model_processors import SalmonProcessor
     from icl_speech_text_llm_amd.data.task_configs import DatasetType, get_dataset_config
