@@ -74,7 +74,18 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="miniature model (smoke only; not a valid bench number)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2s", "c4", "c5"],
+                    help="BASELINE.md §4: c2 = headline (default); c2s = 5 speech exemplars; c4 = Qwen2-Audio HVB; "
+                         "c5 = Llama2-13B VOXCELEB+HVB+VOXPOPULI round-robin")
     return ap.parse_args()
+
+
+WORKLOADS = {   # name -> (description, text tokens per utterance (round-robin list), audios per utterance)
+    "c2": ("C2: SALMONN (Whisper-large-v2 + BEATs + Llama2-7B) speech_only 5-shot VOXCELEB", [288], 1),
+    "c2s": ("C2s: SALMONN-7B speech_only, 5 SPEECH exemplars, VOXCELEB", [200], 6),
+    "c4": ("C4: Qwen2-Audio-7B speech_only 5-shot HVB", [514], 1),
+    "c5": ("C5: SALMONN Llama2-13B, VOXCELEB+HVB+VOXPOPULI round-robin, 5 text exemplars", [288, 512, 320], 1),
+}
 
 
 def synth_utterances(first: int, count: int, vocab: int):
@@ -86,6 +97,29 @@ def synth_utterances(first: int, count: int, vocab: int):
         wav[j] = np.clip(np.random.default_rng(1234 + i).normal(0.0, 0.1, 480000), -1.0, 1.0).astype(np.float32)
         ids[j] = np.random.default_rng(99 + i).integers(3, min(32000, vocab - 1), S_TEXT)
     return wav, ids
+
+
+def synth_workload(first: int, count: int, vocab: int, text_lens, n_audio: int, audio_tokens: int):
+    """Generalisation of synth_utterances for the non-headline workloads: per utterance `n_audio` clips and a prompt of
+    text_lens[i % len] tokens with the audio slots spread through it (exemplars first, query slot 8 tokens before the end)."""
+    from icl_speech_text_llm_amd.runtime.salmonn import speech_segment
+    wav = np.empty((count * n_audio, 480000), dtype=np.float32)
+    prompts = []
+    for j in range(count):
+        i = first + j
+        for a in range(n_audio):
+            wav[j * n_audio + a] = np.clip(np.random.default_rng(1234 + i * 7 + a).normal(0.0, 0.1, 480000), -1.0, 1.0)
+        n = text_lens[i % len(text_lens)]
+        ids = np.random.default_rng(99 + i).integers(3, min(32000, vocab - 1), n).tolist()
+        cuts = [int((n - 8) * (k + 1) / n_audio) for k in range(n_audio)]
+        segs, prev = [], 0
+        for a, c in enumerate(cuts):
+            segs.append(ids[prev:c])
+            segs.append(speech_segment((j * n_audio + a) * audio_tokens, audio_tokens))
+            prev = c
+        segs.append(ids[prev:])
+        prompts.append([sg for sg in segs if not (isinstance(sg, list) and not sg)])
+    return wav, prompts
 
 
 def build_prompts(ids: np.ndarray):
@@ -136,12 +170,23 @@ def main():
     from icl_speech_text_llm_amd.runtime.config import SalmonnCfg
     from icl_speech_text_llm_amd.runtime.salmonn import SalmonnRuntime
 
-    cfg = SalmonnCfg.tiny() if args.tiny else SalmonnCfg.llama2_7b()
-    log(f"building {'tiny' if args.tiny else 'SALMONN-7B'} synthetic weights on {dev} ...")
+    wl_desc, wl_text, wl_naudio = WORKLOADS[args.workload]
+    is_qwen = args.workload == "c4"
+    if is_qwen:
+        from icl_speech_text_llm_amd.runtime.config import QwenAudioCfg
+        from icl_speech_text_llm_amd.runtime.qwen import QwenAudioRuntime
+        cfg = QwenAudioCfg.tiny() if args.tiny else QwenAudioCfg()
+    else:
+        cfg = SalmonnCfg.tiny() if args.tiny else (SalmonnCfg.llama2_13b() if args.workload == "c5" else SalmonnCfg.llama2_7b())
+    log(f"building {'tiny ' if args.tiny else ''}{wl_desc} synthetic weights on {dev} ...")
     t_build = time.perf_counter()
-    sd = synth.salmonn_state(cfg, seed=0, device=dev, dtype=torch.bfloat16)   # identical replica on every rank
-    rt = SalmonnRuntime(cfg, dict(sd), device=dev)
-    want_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline)
+    if is_qwen:
+        sd = synth.qwen_audio_state(cfg, seed=0, device=dev, dtype=torch.bfloat16)
+        rt = QwenAudioRuntime(cfg, dict(sd), device=dev)
+    else:
+        sd = synth.salmonn_state(cfg, seed=0, device=dev, dtype=torch.bfloat16)   # identical replica on every rank
+        rt = SalmonnRuntime(cfg, dict(sd), device=dev)
+    want_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and args.workload == "c2")
     if not want_cpu:
         del sd
     torch.cuda.synchronize()
@@ -150,19 +195,28 @@ def main():
 
     # ---- inputs, resident in HBM before the timed region ----------------------------------------
     Bm, total_steps = args.batch, args.warmup + args.steps
+    vocab = cfg.llm.vocab if is_qwen else cfg.llama.vocab
+    audio_tokens = 750 if is_qwen else N_AUDIO_TOK
     wavs, prompts = [], []
-    lens = [480000] * Bm
+    lens = [480000] * (Bm * wl_naudio)
     for s in range(total_steps):
         first = (s * world + rank) * Bm           # utterance i belongs to rank (i // Bm) % world of step i // (Bm*world)
-        w, ids = synth_utterances(first, Bm, cfg.llama.vocab)
+        if args.workload == "c2":
+            w, ids = synth_utterances(first, Bm, vocab)
+            prompts.append(build_prompts(ids))
+            if s == 0:
+                w0, ids0 = w[0].copy(), ids[0].copy()
+        else:
+            w, pr = synth_workload(first, Bm, vocab, wl_text, wl_naudio, audio_tokens)
+            prompts.append(pr)
         wavs.append(torch.from_numpy(w).to(dev))
-        prompts.append(build_prompts(ids))
-        if s == 0:
-            w0, ids0 = w[0].copy(), ids[0].copy()
     gathered = torch.empty(world * Bm, NEW_TOKENS, dtype=torch.int32, device=dev) if world > 1 else None
 
     def step(s):
-        speech = rt.encode_speech(wavs[s], lens)
+        if is_qwen:
+            speech, _ = rt.encode_audio(raw_wav=wavs[s], wav_lens=lens)
+        else:
+            speech = rt.encode_speech(wavs[s], lens)
         res = rt.generate(prompts[s], speech, max_new_tokens=NEW_TOKENS, suppress_eos=True)
         if world > 1:
             dist.all_gather_into_tensor(gathered, rt.ws.get("gen_tokens", (Bm, NEW_TOKENS), torch.int32))
@@ -240,13 +294,14 @@ def main():
     if rank == 0:
         n_utt = Bm * args.steps * world
         out = {
-            "metric": "ICL utterances/sec (whole node), SALMONN+Llama2-7B 5-shot VOXCELEB",
+            "metric": "ICL utterances/sec (whole node), SALMONN+Llama2-7B 5-shot VOXCELEB" if args.workload == "c2" else
+                      f"ICL utterances/sec (whole node), workload {args.workload}",
             "value": round(n_utt / elapsed, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "C2: SALMONN (Whisper-large-v2 + BEATs + Llama2-7B) speech_only 5-shot VOXCELEB"
-                                   if not args.tiny else "TINY smoke model (not a benchmark)",
-                       "utterances_per_step_per_gpu": Bm, "prompt_positions": S_TEXT + N_AUDIO_TOK,
+            "config": {"workload": wl_desc if not args.tiny else "TINY smoke model (not a benchmark)",
+                       "utterances_per_step_per_gpu": Bm,
+                       "prompt_positions": [t + wl_naudio * audio_tokens for t in wl_text] if len(wl_text) > 1 else wl_text[0] + wl_naudio * audio_tokens,
                        "audio_seconds": 30, "new_tokens": NEW_TOKENS, "parallelism": f"dp{world}",
                        "weights": "seeded N(0,0.02^2) bf16, LoRA r=8 un-merged"},
             "roofline": roof,
