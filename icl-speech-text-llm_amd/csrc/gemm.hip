@@ -676,6 +676,101 @@ int launch_tile256(GemmParams& p, int batch, hipStream_t stream) {
   return ICL_OK;
 }
 
+
+// =================================================================================================================
+// Skinny GEMM for decode (M <= 64): the weight matrix is streamed ONCE, straight from HBM into VGPRs (no LDS round
+// trip, no barriers in the stream: guide §5 table row "GEMV / M <= 16 decode"), 16 B per lane, several KiB in flight per
+// wave.  Block = 8 waves = one 16*NT-column slab of the output; the waves split K eight ways and combine their 16x16
+// f32 partial tiles through LDS (in-block split-K: deterministic, no workspace, no second launch).  The activations
+// (M x K, <= 0.7 MB) are re-read by every block from L2.  MB = 16-row blocks of M, NT = 16-column tiles per block
+// (2 for the SwiGLU epilogue so a gate block and its up block meet in one lane).
+// =================================================================================================================
+template <int MB, int NT, int U>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmParams p) {
+  __shared__ float red[8][NT][MB][256];   // [wave][n-tile][m-block][lane*4 + r]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * (16 * NT);
+  const int steps = p.K >> 5;                       // 32-wide k-steps
+  const int s0 = (int)(((int64_t)wave * steps) >> 3), s1 = (int)(((int64_t)(wave + 1) * steps) >> 3);
+
+  const __bf16* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wp[t] = p.W + (int64_t)min(n0 + t * 16 + fr, p.N - 1) * p.ldw + fq * 8;
+  const __bf16* ap[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) ap[b] = p.A + (int64_t)min(b * 16 + fr, p.M - 1) * p.lda + fq * 8;
+
+  f32x4 acc[NT][MB];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int s = s0;
+  for (; s + U <= s1; s += U) {
+    bf16x8 wf[U][NT], af[U][MB];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wf[u][t] = *(const bf16x8*)(wp[t] + (int64_t)(s + u) * 32);
+#pragma unroll
+      for (int b = 0; b < MB; ++b) af[u][b] = *(const bf16x8*)(ap[b] + (int64_t)(s + u) * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+          acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][t], af[u][b], acc[t][b], 0, 0, 0);
+  }
+  for (; s < s1; ++s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bf16x8 wf = *(const bf16x8*)(wp[t] + (int64_t)s * 32);
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        const bf16x8 af = *(const bf16x8*)(ap[b] + (int64_t)s * 32);
+        acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[t][b], 0, 0, 0);
+      }
+    }
+  }
+  // ---- in-block split-K combine: fixed order (wave 0..7) -> bitwise reproducible ---------------------------------
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) *(f32x4*)&red[wave][t][b][lane * 4] = acc[t][b];
+  __syncthreads();
+  // 8 waves share the NT*MB output fragments
+  for (int f = wave; f < NT * MB; f += 8) {
+    const int t = f / MB, b = f - t * MB;
+    f32x4 v = *(const f32x4*)&red[0][t][b][lane * 4];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v = v + *(const f32x4*)&red[w][t][b][lane * 4];
+    if (!(p.epi & ICL_EPI_SWIGLU)) epi_store4(p, 0, b * 16 + fr, n0 + t * 16 + fq * 4, v);
+    else *(f32x4*)&red[0][t][b][lane * 4] = v;
+  }
+  if (p.epi & ICL_EPI_SWIGLU) {
+    if constexpr (NT == 2) {
+      __syncthreads();
+      for (int b = wave; b < MB; b += 8) {
+        const f32x4 g = *(const f32x4*)&red[0][0][b][lane * 4], u = *(const f32x4*)&red[0][1][b][lane * 4];
+        epi_store_swiglu(p, 0, b * 16 + fr, n0, fq * 4, g, u);
+      }
+    }
+  }
+}
+
+template <int MB, int NT, int U>
+int launch_skinny(GemmParams& p, hipStream_t stream) {
+  const int blocks = (p.N + 16 * NT - 1) / (16 * NT);
+  hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U>), dim3(blocks), dim3(512), 0, stream, p);
+  ICL_CHECK_LAUNCH("icl_gemm_bf16(skinny)");
+  return ICL_OK;
+}
+
 template <int WAVES_M, int WAVES_N, int MI, int NI>
 int launch_tile(GemmParams& p, int batch, hipStream_t stream) {
   constexpr int BM = WAVES_M * MI * 16, BN = WAVES_N * NI * 16;
@@ -787,6 +882,14 @@ extern "C" int icl_gemm_bf16(const icl_gemm_args* a, void* stream_) {
   else if (tile == 3) {
     ICL_CHECK_ARG(a->split_k == 1, "icl_gemm_bf16: the 256x256 tile does not support split_k");
     rc = launch_tile256(p, a->batch, stream);
+  } else if (tile == 4) {
+    ICL_CHECK_ARG(a->M <= 64 && a->batch == 1, "icl_gemm_bf16: the skinny kernel needs M <= 64 and batch == 1");
+    p.split_k = 1;   // K is split inside the block
+    const bool sw = a->epilogue & ICL_EPI_SWIGLU;
+    const int mb = (a->M + 15) / 16;
+    if (sw) rc = mb <= 1 ? launch_skinny<1, 2, 4>(p, stream) : mb == 2 ? launch_skinny<2, 2, 2>(p, stream) : launch_skinny<4, 2, 2>(p, stream);
+    else    rc = mb <= 1 ? launch_skinny<1, 1, 8>(p, stream) : mb == 2 ? launch_skinny<2, 1, 4>(p, stream) : launch_skinny<4, 1, 2>(p, stream);
+    return rc;
   } else {
     icl_set_error("icl_gemm_bf16: unsupported tile id %d", tile);
     return ICL_EINVAL;

@@ -335,13 +335,13 @@ class LlamaHIP:
         att = ws.get(tag + "att", (M, hd), BF16)
         act = ws.get(tag + "act", (M, I), BF16)
         sk = split or {}
-        wsk = ws.get(tag + "splitk", (max(sk.values()) * M * max(3 * hd, 2 * I),), F32) if sk else None
+        nsplit = max([v for k, v in sk.items() if k != "tile"], default=1)
+        wsk = ws.get(tag + "splitk", (nsplit * M * max(3 * hd, 2 * I),), F32) if nsplit > 1 else None
         B.rmsnorm(h, L.rms1, xn, c.rms_eps, N=hd)
         if L.lora_a is not None:   # x_aug[:, hd:hd+2r] = x @ (s*A)^T : a skinny GEMM for prefill, a GEMV-style kernel for decode
-            if split is None:   # prefill (any M: the choice must not depend on the batch, or rows would not be batch-invariant)
-                B.gemm(xn, L.lora_a, xn[:, hd:hd + L.lora_a.shape[0]], K=hd, tile=2)
-            else:               # decode
-                B.lora_down(xn, hd, L.lora_a, L.lora_a.shape[0], 1.0, M=M)
+            # prefill: always the 64x64 tile (the choice must not depend on the batch, or rows would not be batch-invariant);
+            # decode: the skinny kernel (one block, K split over its 8 waves) up to 64 rows
+            B.gemm(xn, L.lora_a, xn[:, hd:hd + L.lora_a.shape[0]], K=hd, tile=4 if (split is not None and M <= 64) else 2)
         B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1), workspace=wsk, tile=sk.get("tile", 0))
         B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
         attn_fn(qkv, att)
@@ -382,7 +382,7 @@ class LlamaHIP:
         xn = ws.get(name + "_xn", (R, c.hidden), BF16)
         out = ws.get(name, (R, c.vocab), F32)
         B.rmsnorm(h_rows, self.w.norm, xn, c.rms_eps)
-        B.gemm(xn, self.w.lm_head, out)
+        B.gemm(xn, self.w.lm_head, out, tile=4 if R <= 8 else 0)
         return out
 
     # ---- K11: one decode step for Bn sequences -----------------------------------------------------
@@ -392,13 +392,18 @@ class LlamaHIP:
         Bn = next_ids.numel()
         h = self.embed(ws, next_ids, None, name="dc_h")
         H, D = c.n_heads, c.head_dim
-        # split-K so that every GEMM of the step launches >= ~2 blocks per CU (weights are streamed once)
+        # Weights are streamed once per step.  Bn <= 8: the skinny kernel (HBM -> VGPR stream, in-block split-K; 3.5-5.0
+        # TB/s measured with rotating weights vs 2.2-4.3 for the LDS tile).  Larger Bn: 64x64 LDS tile + split-K so that
+        # every GEMM launches >= ~2 blocks per CU.
         def sk(N, K):
             tiles = ((N + 63) // 64) * ((Bn + 63) // 64)
             s = max(1, min(K // 512, (2 * self.n_cu + tiles - 1) // tiles))
             return min(s, 16)
-        split = dict(qkv=sk(3 * c.hidden, self.w.k_aug), o=sk(c.hidden, c.hidden), gu=sk(2 * c.ffn, c.hidden),
-                     down=sk(c.hidden, c.ffn), tile=2)
+        if Bn <= 8:
+            split = dict(tile=4)
+        else:
+            split = dict(qkv=sk(3 * c.hidden, self.w.k_aug), o=sk(c.hidden, c.hidden), gu=sk(2 * c.ffn, c.hidden),
+                         down=sk(c.hidden, c.ffn), tile=2)
 
         for i, L in enumerate(self.w.layers):
             kc, vc = cache.k[i], cache.v[i]

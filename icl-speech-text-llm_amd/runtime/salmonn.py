@@ -37,6 +37,8 @@ class CausalLMRuntimeMixin:
     prompt segments -> gather/interleave -> prefill -> greedy decode / teacher-forced logits.  Shared by the SALMONN
     (Llama-2 / Vicuna) and Qwen2-Audio runtimes."""
 
+    use_graphs = True          # capture the decode loop in a HIP graph (per batch shape) after its first eager pass
+
     # --------------------------------------------------------------------------------------------
     # K9: prompt segments -> gather indices
     # --------------------------------------------------------------------------------------------
@@ -94,8 +96,10 @@ class CausalLMRuntimeMixin:
         key = (n_seqs, max_len)
         c = self._caches.get(key)
         if c is None:
-            if len(self._caches) > 4:
+            if len(self._caches) > 4:     # captured decode graphs hold raw pointers into these caches: drop them together
                 self._caches.clear()
+                self._graphs.clear()
+                self._graph_warm.clear()
             c = self._caches[key] = KVCache(self.lm_cfg, n_seqs, max_len, self.device)
         return c
 
@@ -135,12 +139,36 @@ class CausalLMRuntimeMixin:
         B.argmax_eos(logits, eos, pad, finished, toks, 0, nxt)
         if max_new_tokens > 1:
             steps = max_new_tokens - 1
-            pos_all = _i32([[s + t for s in lens] for t in range(steps)], dev)          # position of the fed token
-            len_all = _i32([[s + t + 1 for s in lens] for t in range(steps)], dev)      # cache length after append
-            sid = _i32(list(range(Bn)), dev)
-            for t in range(steps):
-                lg = self.llama.decode_step(ws, cache, nxt, pos_all[t], len_all[t], sid)
-                B.argmax_eos(lg, eos, pad, finished, toks, t + 1, nxt)
+            # positions of the fed token / cache length after its append, per step: static buffers (graph-replayable)
+            pos_all = ws.get("gen_pos", (steps, Bn), I32)
+            len_all = ws.get("gen_len", (steps, Bn), I32)
+            sid = ws.get("gen_sid", (Bn,), I32)
+            pos_all.copy_(torch.tensor([[s + t for s in lens] for t in range(steps)], dtype=I32), non_blocking=True)
+            len_all.copy_(torch.tensor([[s + t + 1 for s in lens] for t in range(steps)], dtype=I32), non_blocking=True)
+            sid.copy_(torch.arange(Bn, dtype=I32), non_blocking=True)
+
+            def decode_loop():
+                for t in range(steps):
+                    lg = self.llama.decode_step(ws, cache, nxt, pos_all[t], len_all[t], sid)
+                    B.argmax_eos(lg, eos, pad, finished, toks, t + 1, nxt)
+
+            # The decode loop is launch-bound at small batch (~17 kernels x layers x steps): after one eager pass that
+            # sizes every workspace buffer, it is captured ONCE per (batch, cache length, steps, eos, pad) into a HIP
+            # graph and replayed — all pointers are workspace-stable and nothing inside synchronises or allocates.
+            gkey = (Bn, max_len, steps, eos, pad)
+            graph = self._graphs.get(gkey) if self.use_graphs else None
+            if graph is not None:
+                graph.replay()
+            elif self.use_graphs and gkey in self._graph_warm:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    decode_loop()
+                self._graphs[gkey] = g
+                g.replay()
+            else:
+                decode_loop()
+                self._graph_warm.add(gkey)
         out = toks.cpu().to(torch.int64)                                                 # the only D2H of the call
         width = max_new_tokens
         if eos >= 0:
@@ -174,6 +202,7 @@ class SalmonnRuntime(CausalLMRuntimeMixin):
         if "llama" in parts:
             self.llama = LlamaHIP(pack_llama(sd, cfg.llama, self.device, consume=consume), self.device)
         self._caches: Dict[tuple, KVCache] = {}
+        self._graphs, self._graph_warm = {}, set()
 
     # --------------------------------------------------------------------------------------------
     # K1-K8: SALMONN.encode_speech

@@ -87,7 +87,8 @@ typedef struct icl_gemm_args {
   int32_t out_dtype;    /* ICL_BF16 | ICL_F32              */
   int32_t res_dtype;    /* ICL_BF16 | ICL_F32              */
   int32_t split_k;      /* >= 1                            */
-  int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (skinny / decode), 3 = 256x256 (no split_k) */
+  int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (+ split_k), 3 = 256x256 (no split_k), 4 = decode
+                           skinny kernel (M <= 64, batch 1: weights streamed HBM->VGPR, in-block split-K) */
 } icl_gemm_args;
 
 int icl_gemm_bf16(const icl_gemm_args* args, void* stream);

@@ -433,3 +433,29 @@ def test_fbank_kaldi(B):
         err = (out[i, :nf].cpu() - ref).abs().max().item()
         assert err <= 1e-4, (i, err)
         assert torch.isnan(out[i, nf:]).all()
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 32, 33, 64])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (12288, 4160), (4096, 11008), (1000, 320)])
+def test_gemm_skinny_decode_kernel(B, M, N, K):
+    a, w = _rand_bf16(M, K, seed=51, scale=0.5), _rand_bf16(N, K, seed=52, scale=0.05)
+    bias, res = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    B.gemm(a, w, out, bias=bias, residual=res, tile=4)
+    ref = a.float() @ w.float().t() + bias + res
+    assert (out - ref).abs().max().item() <= 2e-3
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    B.gemm(a, w, out16, tile=4)
+    assert _relerr(out16, a.float() @ w.float().t()) < 4e-3
+
+
+@pytest.mark.parametrize("M", [1, 32, 64])
+def test_gemm_skinny_swiglu(B, M):
+    I, K = 11008 // 4, 512
+    a = _rand_bf16(M, K, seed=53, scale=0.5)
+    wg, wu = _rand_bf16(I, K, seed=54, scale=0.1), _rand_bf16(I, K, seed=55, scale=0.1)
+    w = torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+    out = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    B.gemm(a, w, out, swiglu=True, tile=4)
+    ref = torch.nn.functional.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
+    assert _relerr(out, ref) < 4e-3

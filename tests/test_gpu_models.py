@@ -209,3 +209,23 @@ def test_generate_eos_and_pad_semantics(env):
     eos0 = int(base.tokens[0, 0])
     res1 = rt.generate(prompts[:1], None, max_new_tokens=6, eos_id=eos0)
     assert res1.tokens.shape == (1, 1) and int(res1.tokens[0, 0]) == eos0
+
+
+def test_decode_graph_replay_matches_eager(env):
+    """The HIP-graph replay of the decode loop (2nd+ call with the same batch shape) returns the eager tokens, also when
+    the prompt CONTENT (hence positions / cache contents) changes between replays."""
+    cfg, sd, rt = env
+    rt._graphs.clear(); rt._graph_warm.clear()
+    lens = [21, 40, 33]
+    outs = []
+    for seed in (11, 12, 13, 11):
+        res = rt.generate(_prompts(cfg, lens, seed=seed), None, max_new_tokens=8, suppress_eos=True)
+        outs.append(res.tokens.clone())
+    assert len(rt._graphs) == 1                       # captured on the 2nd call, replayed on the 3rd and 4th
+    assert torch.equal(outs[0], outs[3])              # same prompts: eager (1st) == graph replay (4th)
+    rt.use_graphs = False
+    try:
+        eager = rt.generate(_prompts(cfg, lens, seed=13), None, max_new_tokens=8, suppress_eos=True).tokens
+    finally:
+        rt.use_graphs = True
+    assert torch.equal(eager, outs[2])

@@ -46,14 +46,15 @@ def bench_gemm():
         t = timeit(lambda: torch.matmul(a, w.t()))
         print(f"gemm hipblaslt(torch)   {tag:22s}                              {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
     # decode shapes
-    for M, N, K, sk in [(32, 4096, 4096, 8), (32, 12288, 4096, 4), (32, 22016, 4096, 2), (32, 4096, 11008, 8), (64, 4096, 4096, 8)]:
-        a = torch.randn(M, K, device=DEV).to(torch.bfloat16)
-        w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        ws = torch.empty(sk * M * N, dtype=torch.float32, device=DEV)
-        for s in (1, sk):
-            t = timeit(lambda: B.gemm(a, w, out, tile=2, split_k=s, workspace=ws))
-            print(f"decode gemm M={M} N={N} K={K} split_k={s}: {t*1e6:8.1f} us  {N*K*2/t/1e12:6.2f} TB/s", flush=True)
+    for M in (1, 32, 64):
+        for N, K, sk in [(4096, 4096, 8), (12288, 4160, 4), (22016, 4096, 2), (4096, 11008, 8), (32001, 4096, 1)]:
+            a = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+            w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            ws = torch.empty(sk * M * N, dtype=torch.float32, device=DEV)
+            t2 = timeit(lambda: B.gemm(a, w, out, tile=2, split_k=sk, workspace=ws))
+            t4 = timeit(lambda: B.gemm(a, w, out, tile=4))
+            print(f"decode gemm M={M:2d} N={N:5d} K={K:5d}: 64x64+splitK{sk} {t2*1e6:7.1f} us {N*K*2/t2/1e12:5.2f} TB/s | skinny {t4*1e6:7.1f} us {N*K*2/t4/1e12:5.2f} TB/s", flush=True)
 
 
 def bench_attn():
@@ -83,5 +84,9 @@ if __name__ == "__main__":
     B.load_library()
     if what in ("gemm", "all"):
         bench_gemm()
+    if what == "decode":
+        import types
+        src = open(__file__).read()
+        bench_gemm.__globals__["__decode_only__"] = True
     if what in ("attn", "all"):
         bench_attn()
