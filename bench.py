@@ -146,9 +146,9 @@ def cpu_baseline(cfg, sd_gpu, wav: np.ndarray, ids: np.ndarray, threads: int):
     llm = om.LlamaOracle(lsd, cfg.llama.n_heads, cfg.llama.rms_eps, cfg.llama.rope_theta, cfg.llama.lora_scale)
     x = torch.cat([llm.embed(torch.from_numpy(ids[:SPEECH_AT])), emb[0], llm.embed(torch.from_numpy(ids[SPEECH_AT:]))])[None]
     log(f"cpu_baseline: speech encoders done at {time.perf_counter() - t0:.1f} s; Llama prefill + decode ...")
-    out = llm.generate_greedy(x, NEW_TOKENS, eos_id=-1, pad_id=cfg.llama.pad_id)
+    out, first = llm.generate_greedy(x, NEW_TOKENS, eos_id=-1, pad_id=cfg.llama.pad_id, return_first_logits=True)
     dt = time.perf_counter() - t0
-    return dt, out[0].tolist()
+    return dt, out[0].tolist(), first[0]
 
 
 def main():
@@ -309,11 +309,20 @@ def main():
         }
         if want_cpu:
             threads = host_cores()
-            dt, cpu_tokens = cpu_baseline(cfg, sd, w0, ids0, threads)
+            dt, cpu_tokens, cpu_first = cpu_baseline(cfg, sd, w0, ids0, threads)
+            # full-size numerical check of the same utterance: GPU first-step logits vs the fp32 CPU oracle
+            sp0 = rt.encode_speech(torch.from_numpy(w0)[None], [480000])
+            g0 = rt.generate(build_prompts(ids0[None]), sp0, max_new_tokens=1, suppress_eos=True, want_first_logits=True)
+            diff = (g0.first_logits[0].cpu() - cpu_first).abs()
+            top2 = cpu_first.topk(2).values
             out["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "utterances/s", "cores": threads, "kind": "port",
                                    "sample": f"1 utterance of the same C2 workload (30 s audio, 376 positions, 10 greedy "
                                              f"tokens), fp32 torch-CPU oracle, {dt:.1f} s",
-                                   "tokens": cpu_tokens, "tokens_match_gpu": cpu_tokens == first_tokens}
+                                   "tokens": cpu_tokens, "tokens_match_gpu": cpu_tokens == first_tokens,
+                                   "first_logits_max_abs_diff_gpu_vs_cpu": round(float(diff.max()), 5),
+                                   "first_logits_rel_l2_diff": round(float(diff.norm() / cpu_first.norm()), 5),
+                                   "cpu_logit_abs_max": round(float(cpu_first.abs().max()), 4),
+                                   "cpu_top1_margin": round(float(top2[0] - top2[1]), 5)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
