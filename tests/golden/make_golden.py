@@ -254,9 +254,87 @@ def g8_clean_prediction():
     for dt in (RefDT.VOXCELEB, RefDT.HVB, RefDT.VOXPOPULI):
         for r in raw:
             table.append({"dataset_type": dt.value, "raw": r, "cleaned": ref_clean(r, dt)})
+    more = raw + ["alpha", "Beta.", "it is gamma", "alpha, beta", "joy", "Sadness!", "12.5 17.25", "3 4 5", "1.234 9",
+                  "PER: 1.5 2.25; ORG: 3 4.125", "per: a b; LOC: 0.5 1", "LAW 1 2", "omega, psi", "phi"]
+    for dt in (RefDT.VOXCELEB_GREEK, RefDT.HVB_GREEK, RefDT.VOXPOPULI_GREEK, RefDT.MELD_EMOTION, RefDT.MELD_EMOTION_GREEK,
+               RefDT.VOXCELEB_SWAP, RefDT.HVB_SWAP, RefDT.SQA, RefDT.VOXPOPULI_NEL, RefDT.VP_NEL, RefDT.MELD, None):
+        for r in more:
+            table.append({"dataset_type": dt.value if dt else None, "raw": r, "cleaned": ref_clean(r, dt)})
     with open(os.path.join(HERE, "clean_prediction.json"), "w") as f:
         json.dump(table, f, indent=1)
     print(f"clean_prediction.json: {len(table)} rows")
+
+
+def g9_metrics():
+    """Seeded prediction tables scored by the reference's own evaluate_predictions / evaluate_vp_nel."""
+    sys.path.insert(0, REF)
+    import pandas as pd
+    from utils.evaluation_utils import evaluate_predictions as ref_eval, evaluate_vp_nel as ref_nel
+    from data.master_config import DatasetType as RefDT, get_dataset_config as ref_cfg, get_swap_config as ref_swap
+    rng = np.random.default_rng(77)
+    cases = []
+
+    def noisy_single(label, labels):
+        r = rng.random()
+        if r < 0.45:
+            return rng.choice([label, label.capitalize() + ".", f"The answer is {label}", f" {label}\nOutput: x"])
+        if r < 0.8:
+            return str(rng.choice(labels))
+        return str(rng.choice(["unknown", "", "maybe", "123", "Postive"]))
+
+    def noisy_multi(gold, labels):
+        r = rng.random()
+        if r < 0.35:
+            return ", ".join(gold)
+        if r < 0.7:
+            k = int(rng.integers(1, 4))
+            return ", ".join(rng.choice(labels, size=k, replace=False).tolist())
+        if r < 0.85:
+            return ",".join(gold[:1]) + ", foo (partial"
+        return str(rng.choice(["none", "nothing here", "", "xyz, abc"]))
+
+    singles = [RefDT.VOXCELEB, RefDT.VOXCELEB_GREEK, RefDT.VOXCELEB_SWAP, RefDT.MELD_EMOTION, RefDT.MELD_EMOTION_GREEK,
+               RefDT.MELD, RefDT.MELD_GREEK]
+    multis = [RefDT.HVB, RefDT.HVB_GREEK, RefDT.HVB_SWAP, RefDT.VOXPOPULI, RefDT.VOXPOPULI_GREEK, RefDT.VOXPOPULI_SWAP]
+    for dt in singles + multis:
+        cfg = ref_swap(dt) if dt in (RefDT.VOXCELEB_SWAP, RefDT.HVB_SWAP, RefDT.VOXPOPULI_SWAP) else ref_cfg(dt)
+        labels = [l.lower() for l in cfg.valid_labels]
+        for n in (1, 7, 48):
+            preds = []
+            for i in range(n):
+                if dt in singles:
+                    gold = str(rng.choice(labels + ["other"])) if rng.random() < 0.1 else str(rng.choice(labels))
+                    preds.append({"text": f"t{i}", "true_label": gold, "predicted_label": noisy_single(gold, labels)})
+                else:
+                    k = int(rng.integers(1, 4))
+                    gold = rng.choice(labels, size=k, replace=False).tolist()
+                    if "VOXPOPULI" in dt.name and rng.random() < 0.2:
+                        gold = ["none"]
+                    if rng.random() < 0.05:
+                        gold = ["bogus"]
+                    preds.append({"text": f"t{i}", "true_label": ", ".join(gold), "predicted_label": noisy_multi(gold, labels)})
+            cases.append({"dataset_type": dt.value, "predictions": preds,
+                          "metrics": ref_eval([dict(p) for p in preds], dt)})
+    for dt in (RefDT.MELD_EMOTION_SWAP, RefDT.VP_NEL, RefDT.VOXPOPULI_NEL):     # the reference's dead ends, kept as they are
+        preds = [{"text": "t", "true_label": "joy", "predicted_label": "joy"}]
+        cases.append({"dataset_type": dt.value, "predictions": preds, "metrics": ref_eval([dict(p) for p in preds], dt)})
+    cases.append({"dataset_type": "voxceleb", "predictions": [], "metrics": ref_eval([], RefDT.VOXCELEB)})
+    nel = []
+    types = ["per", "org", "loc", "law"]
+    for n in (1, 12):
+        gt, pr = [], []
+        for i in range(n):
+            spans = [(str(rng.choice(types)), float(np.round(rng.uniform(0, 10), 2))) for _ in range(int(rng.integers(0, 4)))]
+            g = "; ".join(f"{t.upper()}: {s} {np.round(s + rng.uniform(0.2, 2), 2)}" for t, s in spans)
+            p = "; ".join(f"{(t if rng.random() < 0.8 else 'org').upper()}: {np.round(s + rng.normal(0, 0.15), 2)} "
+                          f"{np.round(s + rng.uniform(0.2, 2), 2)}" for t, s in spans if rng.random() < 0.85)
+            if rng.random() < 0.15:
+                p += "; junk span"
+            gt.append(g); pr.append(p)
+        nel.append({"gt": gt, "pd": pr, "metrics": ref_nel(pd.DataFrame({"gt": gt, "pd": pr}), None)})
+    with open(os.path.join(HERE, "metrics.json"), "w") as f:
+        json.dump({"cases": cases, "vp_nel": nel}, f, indent=0, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+    print(f"metrics.json: {len(cases)} + {len(nel)} cases, {os.path.getsize(os.path.join(HERE, 'metrics.json')) / 1024:.1f} KiB")
 
 
 if __name__ == "__main__":
@@ -267,3 +345,4 @@ if __name__ == "__main__":
     g5_reference_glue()
     g7_qwen2_audio()
     g8_clean_prediction()
+    g9_metrics()

@@ -155,6 +155,38 @@ def test_clean_prediction_matches_reference():
         assert clean_prediction(row["raw"], row["dataset_type"]) == row["cleaned"], row
 
 
+def _same(a, b, path=""):
+    if isinstance(a, dict):
+        assert isinstance(b, dict) and set(a) == set(b), (path, a, b)
+        for k in a:
+            _same(a[k], b[k], f"{path}/{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), (path, a, b)
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f"{path}[{i}]")
+    elif isinstance(a, float) or isinstance(b, float):
+        a, b = float(a), float(b)
+        assert (a != a and b != b) or abs(a - b) <= 1e-12 * max(1.0, abs(a)), (path, a, b)
+    else:
+        assert a == b, (path, a, b)
+
+
+def test_metrics_match_reference_evaluate_predictions():
+    """f1: every score table the reference writes to {run}_metrics.json (utils/evaluation_utils.py:16-467), for all task
+    families incl. greek / swap variants and the reference's dead ends (MELD_EMOTION_SWAP, VP_NEL, VOXPOPULI_NEL, empty)."""
+    from icl_speech_text_llm_amd.utils.evaluation_utils import evaluate_predictions, evaluate_vp_nel
+    g = json.load(open(os.path.join(G, "metrics.json")))
+    assert len(g["cases"]) >= 40
+    for case in g["cases"]:
+        got = evaluate_predictions([dict(p) for p in case["predictions"]], case["dataset_type"])
+        want = case["metrics"]
+        if "error" in want and "error" in got and set(want) == set(got):     # exception texts are scikit-learn's own
+            continue
+        _same(json.loads(json.dumps(got)), want, case["dataset_type"])
+    for case in g["vp_nel"]:
+        _same(json.loads(json.dumps(evaluate_vp_nel(case["gt"], case["pd"]))), case["metrics"], "vp_nel")
+
+
 def test_beats_oracle_self_consistency():
     """BEATs has no upstream source here (parity unpinned vs upstream): check the restated Kaldi fbank against an
     independent straight-line computation of the same published formula, and the bucket function's invariants."""
