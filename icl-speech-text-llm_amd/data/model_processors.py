@@ -9,7 +9,8 @@ MI355X-first difference: the log-mel (K1) moved onto the GPU, so by default the 
 ``raw_wav`` (as float32 — the reference's ``torch.tensor(audio)`` keeps numpy float64) and NO
 ``spectrogram``; DataLoader workers never touch HIP.  Pass ``compute_spectrogram=True`` together with a
 WhisperFeatureExtractor-compatible ``feature_extractor`` to reproduce the reference's CPU behaviour.
-SQA (two-audio) items are out of scope for this round.
+SQA items carry two audios (question + document) per query and per exemplar: ``_format_sqa_prompt`` (:697-740),
+``_process_sqa_inputs`` (:510-614) and ``_collate_sqa_batch`` (:876-1009) are mirrored as well.
 """
 from __future__ import annotations
 
@@ -20,6 +21,10 @@ import torch
 from torch.nn.utils.rnn import pad_sequence
 
 from .task_configs import DatasetType
+
+
+def _is_sqa(dataset_type) -> bool:
+    return dataset_type is not None and str(getattr(dataset_type, "value", dataset_type)) == "sqa"
 
 
 class SalmonProcessor:
@@ -34,6 +39,8 @@ class SalmonProcessor:
     def format_prompt(self, template: str, text: str, examples: Optional[List[Dict]] = None,
                       input_mode: str = "speech_and_text", fewshot_mode: str = "text",
                       dataset_type: Optional[DatasetType] = None, **kwargs) -> str:
+        if _is_sqa(dataset_type):
+            return self._format_sqa_prompt(template, text, examples, input_mode, fewshot_mode, **kwargs)
         examples_text = ""
         if examples:
             if fewshot_mode == "speech":
@@ -49,6 +56,28 @@ class SalmonProcessor:
             input_section = "<Speech><SpeechHere></Speech>"
         return f"{template}\n{examples_text}Now analyze this input:\n{input_section}\nOutput:"
 
+    def _format_sqa_prompt(self, template, text, examples, input_mode, fewshot_mode, **kwargs) -> str:
+        """Character-exact restatement of :697-740, including the stray '>' before the exemplar question marker and the
+        leading blanks of the reference's f-strings (they are part of the tokenised prompt)."""
+        question = kwargs.get("question", "")
+        examples_text = ""
+        if examples:
+            if fewshot_mode == "speech":
+                blocks = [f"Document: <Speech><Document{i}></Speech>\nQuestion: ><Speech><Question{i}></Speech>\n"
+                          f"Output: {ex.get('completion', '')}" for i, ex in enumerate(examples)]
+            else:
+                blocks = [f"Document: {ex.get('document', '')}\nQuestion: {ex.get('question', '')}\n"
+                          f"Output: {ex.get('completion', '')}" for ex in examples]
+            examples_text = "\nHere are few examples to learn from:\n" + "\n\n".join(blocks) + "\n\n"
+        if input_mode == "speech_and_text":
+            input_section = (f"Document: <Speech><Document></Speech>\nDocument text: {text}\n"
+                             f"Question: <Speech><Question></Speech>\nQuestion text: {question}")
+        elif input_mode == "text_only":
+            input_section = f"\nDocument: {text}\nQuestion: {question}"
+        else:
+            input_section = "\nDocument: <Speech><Document></Speech>\n Question: <Speech><Question></Speech>"
+        return f"{template}\n{examples_text} Now analyze this input:\n{input_section}\nOutput:"
+
     # ---- one item ----------------------------------------------------------------------------------
     def _audio(self, audio) -> Dict[str, Any]:
         wav = torch.as_tensor(np.asarray(audio), dtype=torch.float32).reshape(-1)
@@ -58,8 +87,8 @@ class SalmonProcessor:
         return out
 
     def process_inputs(self, data: Dict[str, Any], is_training: bool = False) -> Dict[str, Any]:
-        if data.get("dataset_type") is not None and str(getattr(data["dataset_type"], "value", data["dataset_type"])) == "sqa":
-            raise NotImplementedError("SQA (question+document audio) items are not supported by the MI355X path yet")
+        if _is_sqa(data.get("dataset_type")):
+            return self._process_sqa_inputs(data, is_training)
         input_mode = data.get("input_mode", "speech_only")
         tok = self.tokenizer(data.get("prompt", ""), padding="max_length", truncation=True, max_length=self.max_length,
                              return_tensors="pt")
@@ -72,8 +101,29 @@ class SalmonProcessor:
                 "raw_wav": main["raw_wav"], "wav_length": main["wav_length"], "examples_speech": examples,
                 "num_examples": len(examples), "completion": data.get("completion", "")}
 
+    def _process_sqa_inputs(self, data: Dict[str, Any], is_training: bool = False) -> Dict[str, Any]:
+        input_mode = data.get("input_mode", "speech_only")
+        tok = self.tokenizer(data.get("prompt", ""), padding="max_length", truncation=True, max_length=self.max_length,
+                             return_tensors="pt")
+        none = {"raw_wav": None, "wav_length": 0, "spectrogram": None}
+        audio = data.get("audio") or {}
+        speech = "speech" in input_mode
+        q = self._audio(audio["question_audio"]) if speech and audio.get("question_audio") is not None else dict(none)
+        d = self._audio(audio["document_audio"]) if speech and audio.get("document_audio") is not None else dict(none)
+        examples = []
+        for ex in (data.get("examples_audio") or []):
+            examples.append({"question": self._audio(ex["question_audio"]) if ex.get("question_audio") is not None else dict(none),
+                             "document": self._audio(ex["document_audio"]) if ex.get("document_audio") is not None else dict(none)})
+        self.batch_counter += 1
+        return {"input_ids": tok.input_ids, "attention_mask": tok.attention_mask,
+                "question_spectrogram": q["spectrogram"], "question_raw_wav": q["raw_wav"], "question_wav_length": q["wav_length"],
+                "document_spectrogram": d["spectrogram"], "document_raw_wav": d["raw_wav"], "document_wav_length": d["wav_length"],
+                "examples_speech": examples, "num_examples": len(examples), "completion": data.get("completion", "")}
+
     # ---- batch -------------------------------------------------------------------------------------
     def collate_batch(self, items: List[Dict[str, Any]]) -> Dict[str, Any]:
+        if _is_sqa(items[0].get("dataset_type")):
+            return self._collate_sqa_batch(items)
         batch: Dict[str, Any] = {
             "input_ids": torch.stack([it["input_ids"] for it in items]),
             "attention_mask": torch.stack([it["attention_mask"] for it in items]),
@@ -111,6 +161,45 @@ class SalmonProcessor:
                 batch["example_spectrograms"] = torch.stack(ex_specs)
         batch["num_examples"] = torch.tensor([it["num_examples"] for it in items])
         for key in ("prompt", "completion", "text", "dataset_type"):
+            if key in items[0]:
+                batch[key] = [it[key] for it in items]
+        return batch
+
+
+    def _collate_sqa_batch(self, items: List[Dict[str, Any]]) -> Dict[str, Any]:
+        batch: Dict[str, Any] = {"input_ids": torch.stack([it["input_ids"] for it in items]),
+                                 "attention_mask": torch.stack([it["attention_mask"] for it in items])}
+        if all(it.get("question_raw_wav") is not None and it.get("document_raw_wav") is not None for it in items):
+            for side in ("question", "document"):
+                lens = torch.tensor([it[f"{side}_wav_length"] for it in items])
+                wavs = pad_sequence([it[f"{side}_raw_wav"] for it in items], batch_first=True, padding_value=0.0)
+                batch[f"{side}_wav_lengths"], batch[f"{side}_raw_wav"] = lens, wavs
+                batch[f"{side}_padding_mask"] = torch.arange(wavs.size(1)).unsqueeze(0) >= lens.unsqueeze(1)
+                if all(it.get(f"{side}_spectrogram") is not None for it in items):
+                    batch[f"{side}_spectrogram"] = torch.stack([it[f"{side}_spectrogram"] for it in items])
+        max_examples = max(it["num_examples"] for it in items)
+        if max_examples > 0 and any(it.get("examples_speech") and all(ex[s]["raw_wav"] is not None for ex in it["examples_speech"]
+                                                                        for s in ("question", "document")) for it in items):
+            for side in ("question", "document"):
+                exs = [[ex[side] for ex in it.get("examples_speech", [])[:it["num_examples"]]] for it in items]
+                max_len = max(e["wav_length"] for row in exs for e in row)
+                have_spec = all(e["spectrogram"] is not None for row in exs for e in row)
+                w = torch.zeros(len(items), max_examples, max_len)
+                m = torch.ones(len(items), max_examples, max_len, dtype=torch.bool)
+                l = torch.zeros(len(items), max_examples, dtype=torch.long)
+                sp = torch.zeros(len(items), max_examples, 80, 3000) if have_spec else None
+                for b, row in enumerate(exs):
+                    for e, ex in enumerate(row):
+                        n = ex["wav_length"]
+                        w[b, e, :n], m[b, e, :n], l[b, e] = ex["raw_wav"], False, n
+                        if have_spec:
+                            sp[b, e] = ex["spectrogram"]
+                batch[f"example_{side}_wavs"], batch[f"example_{side}_padding_masks"] = w, m
+                batch[f"example_{side}_wav_lengths"] = l
+                if have_spec:
+                    batch[f"example_{side}_spectrograms"] = sp
+        batch["num_examples"] = torch.tensor([it["num_examples"] for it in items])
+        for key in ("prompt", "completion", "text", "question", "dataset_type"):
             if key in items[0]:
                 batch[key] = [it[key] for it in items]
         return batch

@@ -72,3 +72,116 @@ class SyntheticICLDataset(Dataset):
                                               "completion": label, "input_mode": self.input_mode, "dataset_type": dt})
         item.update({"prompt": prompt, "completion": label, "text": text, "dataset_type": dt})
         return item
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# On-disk stand-ins with the reference's column schema (for ``--dataset_root`` runs, tests and golden generation)
+# ---------------------------------------------------------------------------------------------------------------------
+def _sentence(rng, n_chars: int) -> str:
+    out = ""
+    while len(out) < n_chars:
+        out += ("" if not out else " ") + _WORDS[int(rng.integers(len(_WORDS)))]
+    return out[:n_chars].strip()
+
+
+def _clip(rng, seconds) -> Dict[str, Any]:
+    n = int(round(float(rng.uniform(*seconds)) * 16000))
+    return {"array": np.clip(rng.normal(0.0, 0.1, n), -1.0, 1.0).astype(np.float32).tolist(), "sampling_rate": 16000}
+
+
+def _ner_row(rng, text: str, tags: List[str]):
+    """A ``normalized_combined_ner`` cell: character spans of whole words of ``text`` with entity tags."""
+    words, pos, spans = text.split(" "), 0, []
+    for w in words:
+        if w and rng.random() < 0.25:
+            spans.append((str(rng.choice(tags)), pos, len(w)))
+        pos += len(w) + 1
+    return {"type": [s[0] for s in spans], "start": [s[1] for s in spans], "length": [s[2] for s in spans]}
+
+
+def write_synthetic_hf_datasets(root: str, dataset_types: Sequence[DatasetType], n_items: int = 6, n_lookup: int = 8,
+                                n_fewshot: int = 6, audio_seconds=(0.2, 0.6), seed: int = 0, splits=("test",)) -> None:
+    """Writes, under ``root``, one HF ``datasets`` folder per (base task, split) plus its audio-lookup folder, named by the
+    basenames of the reference's configured paths, with the columns the reference's item pipeline reads
+    (data/multi_task_dataset.py:231-462): ``<text_key>``, ``<completion_key>``, ``audio{array,sampling_rate}``,
+    ``few_shot_examples[{text,label,index}]`` and, in the lookup folder, ``index`` + ``audio`` (+ text / label columns for
+    the tasks whose exemplars are sampled from it).  Audio is seeded noise stored as plain float lists (the image has no
+    audio decoder, so the HF ``Audio`` feature is not used)."""
+    import os
+    import zlib
+    import datasets
+    from datasets import Dataset as HFDataset
+    datasets.disable_progress_bars()
+    from .task_configs import DatasetSplit, base_type_for_loading, set_dataset_root
+    done = set()
+    set_dataset_root(root)
+    for dt in dataset_types:
+        base = base_type_for_loading(dt)
+        if base in done:
+            continue
+        done.add(base)
+        cfg = get_dataset_config(base)
+        name = base.name
+        for split in splits:
+            sp = DatasetSplit({"val": "validation"}.get(split, split))
+            if sp not in cfg.paths or os.path.exists(cfg.get_path(sp)):
+                continue                    # variants that share their base task's folders (e.g. MELD_GREEK) reuse them
+            rng = np.random.default_rng(seed + zlib.crc32(os.path.basename(cfg.get_path(sp)).encode()))
+            labels = list(cfg.label_mapping) if cfg.label_mapping else (cfg.valid_labels or [])   # folders hold base labels
+            kind = cfg.completion_key
+
+            def label_cell(text):
+                if kind in ("sentiment", "sentiment_label", "emotion_label"):
+                    return str(rng.choice(labels))
+                if kind == "dialog_acts":
+                    return rng.choice(labels, size=int(rng.integers(1, 4)), replace=False).tolist()
+                if kind == "normalized_combined_ner":
+                    return _ner_row(rng, text, labels)
+                if kind == "answer_text":
+                    s = float(np.round(rng.uniform(0, 20), 2))
+                    return f"{s} {float(np.round(s + rng.uniform(0.3, 3), 2))}"
+                if kind == "ne_spans":
+                    return [{"label": str(rng.choice(["PER", "ORG", "LOC"])), "time_span": [float(np.round(t, 2)), float(np.round(t + 0.5, 2))]}
+                            for t in rng.uniform(0, 5, int(rng.integers(0, 3)))]
+                raise ValueError(f"no synthetic schema for {name} ({kind})")
+
+            def example_label(text):        # the form exemplar labels take inside ``few_shot_examples``
+                cell = label_cell(text)
+                if kind == "normalized_combined_ner":
+                    got = {}
+                    for tag, start, length in zip(cell["type"], cell["start"], cell["length"]):
+                        got.setdefault(tag, []).append(text[start:start + length])
+                    return {tag: got.get(tag) for tag in labels}
+                return cell
+
+            lookup_rows = []
+            for i in range(n_lookup):
+                text = _sentence(rng, int(rng.integers(30, 70)))
+                row = {"index": str(1000 + i), cfg.text_key: text, cfg.completion_key: label_cell(text)}
+                if kind == "answer_text":
+                    row.update({cfg.additional_text_keys["question"]: _sentence(rng, 25), "question_audio": _clip(rng, audio_seconds),
+                                "document_audio": _clip(rng, audio_seconds), "unique_id": f"lk{i}"})
+                else:
+                    row["audio"] = _clip(rng, audio_seconds)
+                lookup_rows.append(row)
+            rows = []
+            for i in range(n_items):
+                text = _sentence(rng, int(rng.integers(40, 76)))
+                row = {cfg.text_key: text, cfg.completion_key: label_cell(text)}
+                if kind == "answer_text":
+                    row.update({cfg.additional_text_keys["question"]: _sentence(rng, 25), "question_audio": _clip(rng, audio_seconds),
+                                "document_audio": _clip(rng, audio_seconds), "unique_id": f"it{i}", "question_id": f"q{i}",
+                                "document_id": f"d{i}"})
+                else:
+                    row["audio"] = _clip(rng, audio_seconds)
+                    if kind == "ne_spans":
+                        row.update({"unique_id": f"it{i}", "speaker_id": f"s{i % 3}"})
+                    shots = []
+                    for j in rng.choice(n_lookup, size=min(n_fewshot, n_lookup), replace=False):
+                        t = lookup_rows[int(j)][cfg.text_key]
+                        shots.append({"text": t, "label": example_label(t), "index": lookup_rows[int(j)]["index"]})
+                    row["few_shot_examples"] = shots
+                rows.append(row)
+            for path, table in ((cfg.get_path(sp), rows), (cfg.get_audio_lookup_path(sp), lookup_rows)):
+                if path and not os.path.exists(path):
+                    HFDataset.from_list(table).save_to_disk(path)

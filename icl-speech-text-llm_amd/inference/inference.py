@@ -3,9 +3,11 @@
 
 Differences, all additive:
   * ``--results_dir`` replaces the hard-coded ``/data2/.../metrics/{today}`` (:132);
-  * datasets: the authors' HF ``datasets`` folders are not reachable here, so the CLI runs on the seeded
-    ``SyntheticICLDataset`` (same item schema, same prompt templates) unless ``--dataset_root`` points at real data
-    (real-data loading is the "next" row f2 of SURVEY.md §8 and is not implemented yet);
+  * datasets: ``--dataset_root DIR`` re-roots the reference's hard-coded cluster paths (data/*_config.py) to
+    ``DIR/<same folder name>`` and runs the reference's item pipeline (``load_dataset`` → ``DatasetFactory`` →
+    ``InferenceDataset`` / ``MultiTaskInferenceDataset``); ``--write_synthetic_datasets`` first fills DIR
+    with seeded stand-in folders of the same column schema.  Without ``--dataset_root`` the CLI runs on the in-memory
+    ``SyntheticICLDataset`` (same item schema and prompt templates, 30 s clips);
   * data-parallel inference: launched under ``torchrun`` (one process per GPU) the utterances are sharded
     ``i ≡ rank (mod world)`` and rank 0 gathers every rank's results before scoring (the reference's inference is
     single-process); ``--batch_size`` defaults to 16 because ragged prompts batch fine on this path.
@@ -28,7 +30,9 @@ from torch.utils.data import DataLoader, Subset
 from ..config.inference_config import get_inference_config
 from ..data.model_processors import get_processor
 from ..data.synthetic_dataset import SyntheticICLDataset
-from ..data.task_configs import DatasetType, parse_dataset_types
+from ..data.dataset_factory import DatasetFactory
+from ..data.task_configs import DatasetType, parse_dataset_types, set_dataset_root
+from ..utils.data_utils import load_dataset
 from ..models.model_factory import ModelFactory, load_finetuned_checkpoint
 from ..utils.evaluation_utils import clean_prediction, evaluate_predictions
 from ..utils.performance_utils import PerformanceTracker
@@ -70,7 +74,9 @@ def parse_args(argv=None):
     p.add_argument("--interleave", type=_bool, default=False)
     # additions
     p.add_argument("--results_dir", type=str, default=None, help="default: ./results/{today}")
-    p.add_argument("--dataset_root", type=str, default=None, help="root of real HF datasets (not implemented yet)")
+    p.add_argument("--dataset_root", type=str, default=None, help="folder holding the tasks' HF datasets folders")
+    p.add_argument("--write_synthetic_datasets", action="store_true",
+                   help="fill --dataset_root with seeded synthetic folders of the reference's column schema first")
     p.add_argument("--synthetic_items", type=int, default=64, help="items per task of the synthetic dataset")
     p.add_argument("--arch", type=str, default=None, help="7b | 13b | tiny (default: inferred from llama_path)")
     p.add_argument("--max_new_tokens", type=int, default=10)
@@ -116,11 +122,30 @@ def run_inference(args) -> Dict[str, Any]:
             processor = get_processor(args.model_type, model.input_processor)
             args.num_workers = 0
         if args.dataset_root:
-            raise NotImplementedError("real-dataset loading (SURVEY.md §8 f2) is not implemented; omit --dataset_root")
-        n_items = args.debug_samples if args.debug_samples and args.debug_samples > 0 else args.synthetic_items
-        dataset = SyntheticICLDataset(processor, dataset_types, n_items=n_items, num_examples=args.num_examples,
-                                      input_mode=args.input_mode, fewshot_mode=args.fewshot_mode, seed=1234,
-                                      interleave=args.interleave)
+            set_dataset_root(args.dataset_root)
+            if args.write_synthetic_datasets:
+                if rank == 0:
+                    from ..data.synthetic_dataset import write_synthetic_hf_datasets
+                    write_synthetic_hf_datasets(args.dataset_root, dataset_types, n_items=args.synthetic_items,
+                                                n_lookup=max(8, args.num_examples + 3), n_fewshot=max(args.num_examples, 5),
+                                                audio_seconds=(2.0, 8.0), splits=(args.split,))
+                if dist is not None:
+                    dist.barrier()
+            rows = {}
+            for dt in dataset_types:                                   # reference: inference.py:204-218
+                full = load_dataset(dt, split=args.split)
+                rows[dt] = full.select(range(args.debug_samples)) if args.debug_samples and args.debug_samples > 0 else full
+                logger.info("Loaded dataset %s: %d examples", dt, len(rows[dt]))
+            dataset = DatasetFactory.create_dataset(
+                dataset_type=dataset_types, dataset=rows, processor=processor, is_training=False,
+                input_mode=args.input_mode, fewshot_mode=args.fewshot_mode, num_examples=args.num_examples,
+                random_examples=False, model_type=args.model_type, run_name=args.run_name,
+                randomize_swap=args.randomize_swap, balance_datasets=args.balance_datasets, interleave=args.interleave)
+        else:
+            n_items = args.debug_samples if args.debug_samples and args.debug_samples > 0 else args.synthetic_items
+            dataset = SyntheticICLDataset(processor, dataset_types, n_items=n_items, num_examples=args.num_examples,
+                                          input_mode=args.input_mode, fewshot_mode=args.fewshot_mode, seed=1234,
+                                          interleave=args.interleave)
         total = len(dataset) if args.max_samples is None else min(len(dataset), args.max_samples)
         indices = list(range(rank, total, world))     # shard by rank, no padding duplicates
         loader = DataLoader(Subset(dataset, indices), batch_size=args.batch_size, shuffle=False,

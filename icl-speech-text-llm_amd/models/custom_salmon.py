@@ -12,7 +12,7 @@ Reference behaviour kept (file:line of /root/reference/models/custom_salmon.py):
     ``input_processor``.
 Deliberate differences: the serial B x E ``encode_speech`` loop (:503-519) is one batched kernel chain; prompts of
 different lengths in one batch are allowed (the reference's ``torch.stack`` :299 forbids them); the first-batch debug
-logging with its ``.item()`` syncs is dropped; SQA two-audio prompts and sampling are not implemented.
+logging with its ``.item()`` syncs is dropped; SQA batches must carry raw waveforms (the log-mel is computed on the GPU).
 """
 from __future__ import annotations
 
@@ -36,12 +36,22 @@ logger = logging.getLogger(__name__)
 # ------------------------------------------------------------------------------------------------------
 # host-side prompt logic (pure Python: testable without a GPU, pinned to the reference by golden captures)
 # ------------------------------------------------------------------------------------------------------
-def split_prompt(prompt: str, max_examples: int, has_example_embeds: bool, speech_placeholder: str = "<SpeechHere>") -> List[str]:
-    """Text parts of one prompt, exactly as custom_prompt_wrap cuts them (reference :131-175, non-SQA branch)."""
+def split_prompt(prompt: str, max_examples: int, has_example_embeds: bool, speech_placeholder: str = "<SpeechHere>",
+                 is_sqa: bool = False) -> List[str]:
+    """Text parts of one prompt, exactly as custom_prompt_wrap cuts them (reference :131-175).  ``is_sqa`` is the
+    reference's ``isinstance(embeds, tuple)``: exemplars are cut at ``<Document{i}>`` then ``<Question{i}>`` (two parts
+    each); the query is cut at ``<Document>`` then ``<Question>`` whenever ``<Question>`` occurs in what is left."""
     parts: List[str] = []
     suffix = prompt
     if max_examples > 0 and has_example_embeds:
         for i in range(max_examples):
+            if is_sqa:
+                q_marker, d_marker = f"<Question{i}>", f"<Document{i}>"
+                if q_marker in suffix and d_marker in suffix:
+                    before_d, rest = suffix.split(d_marker, 1)
+                    middle, suffix = rest.split(q_marker, 1)
+                    parts += [before_d, middle]
+                continue
             marker = f"<Example{i}>"
             if marker in suffix:
                 before, suffix = suffix.split(marker, 1)
@@ -49,8 +59,10 @@ def split_prompt(prompt: str, max_examples: int, has_example_embeds: bool, speec
             else:
                 parts.append("")
     if "<Question>" in suffix:
-        raise NotImplementedError("SQA prompts (<Document>/<Question>) are not supported by the MI355X path yet")
-    if speech_placeholder in suffix:
+        before_d, rest = suffix.split("<Document>", 1)
+        middle, suffix = rest.split("<Question>", 1)
+        parts += [before_d, middle]
+    elif speech_placeholder in suffix:
         before, suffix = suffix.split(speech_placeholder)   # ValueError on a repeated placeholder, as in the reference
         parts.append(before)
     else:
@@ -73,6 +85,22 @@ def interleave_plan(n_parts: int, max_examples: int, n_example_embeds: Optional[
         plan += [("text", n_parts - 2), ("text", n_parts - 1)]
     else:
         plan.append(("text", n_parts - 1))
+    return plan
+
+
+def interleave_plan_sqa(n_parts: int, max_examples: int, n_example_embeds: Optional[int], has_main_speech: bool) -> List[Tuple[str, int]]:
+    """SQA order (reference :206-241): per exemplar ``text 2i, document audio, text 2i+1, question audio`` (the text between
+    them is dropped with the audios when the row has no embedding for exemplar i), then
+    ``text[-3], document, text[-2], question, text[-1]``.  Kinds: 'text' | 'example_d' | 'example_q' | 'speech_d' | 'speech_q'."""
+    plan: List[Tuple[str, int]] = []
+    for i in range(max_examples):
+        plan.append(("text", 2 * i))
+        if n_example_embeds is not None and i < n_example_embeds:
+            plan += [("example_d", i), ("text", 2 * i + 1), ("example_q", i)]
+    if has_main_speech:
+        plan += [("text", n_parts - 3), ("speech_d", 0), ("text", n_parts - 2), ("speech_q", 0), ("text", n_parts - 1)]
+    else:
+        plan += [("text", n_parts - 3), ("text", n_parts - 2), ("text", n_parts - 1)]
     return plan
 
 
@@ -253,8 +281,8 @@ class CustomSALMONN(BaseModel):
 
     def get_speech_embeddings(self, samples: Dict[str, Any]):
         t0 = time.time()
-        if "question_spectrogram" in samples or "document_spectrogram" in samples:
-            raise NotImplementedError("SQA (question/document audio) batches are not supported by the MI355X path yet")
+        if any(k in samples for k in ("question_raw_wav", "question_spectrogram", "example_question_wavs")):
+            return self._sqa_speech_embeddings(samples)
         main_wav, main_spec = samples.get("raw_wav"), samples.get("spectrogram")
         has_main = main_wav is not None or main_spec is not None
         ex_wav, ex_spec = samples.get("example_wavs"), samples.get("example_spectrograms")
@@ -310,6 +338,58 @@ class CustomSALMONN(BaseModel):
         logger.debug("Speech embedding generation took %.3f s", time.time() - t0)
         return speech_embeds, speech_atts, example_embeds, example_atts
 
+    def _sqa_speech_embeddings(self, samples: Dict[str, Any]):
+        """SQA batches (reference :312-323, :383-404, :444-488): question and document audio of the query and of every speech
+        exemplar, all encoded in ONE batched kernel chain; returns ``((q, d), (q_atts, d_atts), [[(q_e, d_e)…]…], atts)``."""
+        rt = self.runtime
+        ntok = rt.tokens_per_audio
+        q_wav, d_wav = samples.get("question_raw_wav"), samples.get("document_raw_wav")
+        eq_wav, ed_wav = samples.get("example_question_wavs"), samples.get("example_document_wavs")
+        has_main = q_wav is not None and d_wav is not None
+        has_ex = eq_wav is not None and ed_wav is not None
+        if not has_main and not has_ex:
+            if samples.get("question_spectrogram") is not None:
+                raise NotImplementedError("SQA batches must carry raw waveforms: the MI355X path computes the log-mel itself")
+            return None, None, None, None
+        rows, valid, padded, owners = [], [], [], []
+        if has_main:
+            B = q_wav.shape[0]
+            for side, wav in (("q", q_wav), ("d", d_wav)):
+                name = "question" if side == "q" else "document"
+                lens = self._lengths(wav, samples.get(f"{name}_wav_lengths"), samples.get(f"{name}_padding_mask"))
+                for b in range(B):
+                    rows.append(wav[b]); valid.append(lens[b]); padded.append(wav.shape[1]); owners.append((b, side, -1))
+        if has_ex:
+            B, E = eq_wav.shape[:2]
+            nex = samples.get("num_examples")
+            for side, wav in (("q", eq_wav), ("d", ed_wav)):
+                name = "question" if side == "q" else "document"
+                lens = self._lengths(wav, samples.get(f"example_{name}_wav_lengths"), samples.get(f"example_{name}_padding_masks"))
+                for b in range(B):
+                    for e in range(min(E, int(nex[b]) if nex is not None else E)):
+                        rows.append(wav[b, e]); valid.append(lens[b * E + e]); padded.append(wav.shape[2]); owners.append((b, side, e))
+        L = max(r.shape[0] for r in rows)
+        wav = torch.zeros(len(rows), L, dtype=torch.float32, device=self.device)
+        for i, r in enumerate(rows):
+            wav[i, :r.shape[0]] = r.to(device=self.device, dtype=torch.float32)
+        emb = rt.encode_speech(wav, valid, padded_lens=padded).clone()
+        ones = torch.ones(ntok, dtype=torch.long, device=emb.device)
+        speech_embeds = speech_atts = example_embeds = example_atts = None
+        if has_main:
+            B = q_wav.shape[0]
+            speech_embeds = (emb[:B], emb[B:2 * B])
+            speech_atts = (torch.ones(B, ntok, dtype=torch.long, device=emb.device),) * 2
+        if has_ex:
+            B = eq_wav.shape[0]
+            slot: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
+            for i, (b, side, e) in enumerate(owners):
+                if e >= 0:
+                    slot.setdefault((b, e), {})[side] = emb[i]
+            example_embeds = [[(slot[(b, e)]["q"], slot[(b, e)]["d"]) for e in sorted(k[1] for k in slot if k[0] == b)]
+                              for b in range(B)]
+            example_atts = [[(ones, ones) for _ in row] for row in example_embeds]
+        return speech_embeds, speech_atts, example_embeds, example_atts
+
     # ---- prompt wrap ------------------------------------------------------------------------------------
     def _segments(self, embeds, prompts: Sequence[str], num_examples, example_embeds):
         """Per-row segment lists for the K9 gather + the flat speech-row matrix they index."""
@@ -318,18 +398,22 @@ class CustomSALMONN(BaseModel):
         speech_rows: List[torch.Tensor] = []
         n_rows = 0
         all_segments = []
+        is_sqa = isinstance(embeds, tuple)
         for b, prompt in enumerate(prompts):
-            parts = split_prompt(prompt, max_examples, example_embeds is not None, self.speech_placeholder)
+            parts = split_prompt(prompt, max_examples, example_embeds is not None, self.speech_placeholder, is_sqa=is_sqa)
             ids = [self.llama_tokenizer(p, padding="longest", return_tensors="pt", add_special_tokens=False)["input_ids"]
                    .reshape(-1).tolist() for p in parts]
             n_ex = len(example_embeds[b]) if (example_embeds is not None and b < len(example_embeds)) else None
             segs = []
-            for kind, i in interleave_plan(len(parts), max_examples, n_ex, embeds is not None):
+            plan = (interleave_plan_sqa if is_sqa else interleave_plan)(len(parts), max_examples, n_ex, embeds is not None)
+            for kind, i in plan:
                 if kind == "text":
                     if ids[i]:
                         segs.append(ids[i])
                 else:
-                    t = embeds[b] if kind == "speech" else example_embeds[b][i]
+                    t = {"speech": lambda: embeds[b], "example": lambda: example_embeds[b][i],
+                         "speech_q": lambda: embeds[0][b], "speech_d": lambda: embeds[1][b],
+                         "example_q": lambda: example_embeds[b][i][0], "example_d": lambda: example_embeds[b][i][1]}[kind]()
                     speech_rows.append(t)
                     segs.append(speech_segment(n_rows, t.shape[0]))
                     n_rows += t.shape[0]

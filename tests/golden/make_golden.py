@@ -191,6 +191,44 @@ def g5_reference_glue():
         cases[case] = {"prompt": prompt, "completion": "positive", "generated_text": gen[0],
                        "num_examples": int(samples["num_examples"][0]), "S": int(wrapped.shape[1])}
         save(f"glue_{case}.npz", **arrs)
+    # SQA: two audios (question + document) per query and per speech exemplar (custom_salmon.py:135-149,206-241,383-404,444-488)
+    sqa_t = ref_cfg(RefDT.SQA).prompt_template
+    sqa_ex = [{"question": f"what about item {i}", "document": f"the document number {i} says things", "completion": f"{i}.5 {i + 2}.25"}
+              for i in range(2)]
+    for case, (mode, few) in {"sqa_speech_text_ex": ("speech_only", "text"), "sqa_speech_speech_ex": ("speech_only", "speech"),
+                              "sqa_speechtext_zero": ("speech_and_text", "zero")}.items():
+        exs = None if few == "zero" else sqa_ex
+        prompt = rproc._format_sqa_prompt(sqa_t, "the document text to search", exs, mode, "text" if few == "zero" else few,
+                                          question="where is the answer")
+        E = len(sqa_ex) if few == "speech" else 0
+        samples = {"prompt": [prompt], "completion": ["3.5 4.75"], "num_examples": torch.tensor([E]),
+                   "question_spectrogram": torch.randn(1, 80, 3000) * 0.5, "document_spectrogram": torch.randn(1, 80, 3000) * 0.5,
+                   "question_raw_wav": torch.zeros(1, 8000), "document_raw_wav": torch.zeros(1, 12000),
+                   "question_padding_mask": torch.zeros(1, 8000, dtype=torch.bool),
+                   "document_padding_mask": torch.zeros(1, 12000, dtype=torch.bool)}
+        if E:
+            samples.update({"example_question_spectrograms": torch.randn(1, E, 80, 3000) * 0.5,
+                            "example_document_spectrograms": torch.randn(1, E, 80, 3000) * 0.5,
+                            "example_question_wavs": torch.zeros(1, E, 8000), "example_document_wavs": torch.zeros(1, E, 8000),
+                            "example_question_padding_masks": torch.zeros(1, E, 8000, dtype=torch.bool),
+                            "example_document_padding_masks": torch.zeros(1, E, 8000, dtype=torch.bool)})
+        with torch.no_grad():
+            ref.batch_counter = 1
+            sp, sa, ee, ea = ref.get_speech_embeddings(dict(samples))
+            wrapped, watts = ref.custom_prompt_wrap(sp, sa, samples["prompt"], samples["num_examples"], ee, ea)
+            fwd = ref.forward(dict(samples))
+            gen = ref.generate_output(dict(samples))
+            gen_ids = ref.llama_model.generate(inputs_embeds=wrapped, attention_mask=watts, max_new_tokens=10, num_beams=1,
+                                               do_sample=False, min_length=1, pad_token_id=tok.pad_token_id,
+                                               eos_token_id=tok.eos_token_id)
+        arrs = dict(wrapped=wrapped[0], logits_tail=fwd["logits"][0, -12:], labels=fwd["labels"][0], loss=fwd["loss"],
+                    gen_ids=gen_ids[0], speech_q=sp[0][0], speech_d=sp[1][0])
+        if ee is not None:
+            arrs["examples_q"] = torch.stack([e[0] for e in ee[0]])
+            arrs["examples_d"] = torch.stack([e[1] for e in ee[0]])
+        cases[case] = {"prompt": prompt, "completion": "3.5 4.75", "generated_text": gen[0], "num_examples": E,
+                       "S": int(wrapped.shape[1]), "sqa": True}
+        save(f"glue_{case}.npz", **arrs)
     save("glue_llama.npz", **{"w:" + k: v for k, v in llama.state_dict().items()})
     with open(os.path.join(HERE, "glue_cases.json"), "w") as f:
         json.dump(cases, f, indent=1)
@@ -202,6 +240,10 @@ def g5_reference_glue():
             for few in ("text", "speech"):
                 fmt[f"{dt.value}|{mode}|{few}"] = rproc._format_default_prompt(t, "query text", ex[:3], mode, few)
         fmt[f"{dt.value}|speech_only|zero"] = rproc._format_default_prompt(t, "query text", None, "speech_only", "text")
+    for mode in ("speech_only", "text_only", "speech_and_text"):
+        for few in ("text", "speech"):
+            fmt[f"sqa|{mode}|{few}"] = rproc._format_sqa_prompt(sqa_t, "document text", sqa_ex, mode, few, question="the question")
+    fmt["sqa|speech_only|zero"] = rproc._format_sqa_prompt(sqa_t, "document text", None, "speech_only", "text", question="the question")
     with open(os.path.join(HERE, "format_prompt.json"), "w") as f:
         json.dump(fmt, f, indent=1)
 
@@ -337,6 +379,112 @@ def g9_metrics():
     print(f"metrics.json: {len(cases)} + {len(nel)} cases, {os.path.getsize(os.path.join(HERE, 'metrics.json')) / 1024:.1f} KiB")
 
 
+DATASET_CASES = [   # (tasks, input_mode, fewshot_mode, num_examples, balance, interleave)
+    (["voxceleb"], "speech_only", "text", 5, False, False),
+    (["voxceleb"], "speech_only", "speech", 3, False, False),
+    (["voxceleb"], "text_only", "text", 2, False, False),
+    (["voxceleb"], "speech_and_text", "text", 0, False, False),
+    (["voxceleb_greek"], "speech_only", "text", 5, False, False),
+    (["voxceleb_swap"], "speech_only", "text", 4, False, False),
+    (["hvb"], "speech_only", "text", 5, False, False),
+    (["hvb_greek"], "text_only", "text", 3, False, False),
+    (["hvb_swap"], "speech_only", "speech", 2, False, False),
+    (["voxpopuli"], "speech_only", "text", 5, False, False),
+    (["voxpopuli_greek"], "speech_and_text", "text", 3, False, False),
+    (["voxpopuli_swap"], "speech_only", "text", 3, False, False),
+    (["meld"], "speech_only", "text", 3, False, False),
+    (["meld_greek"], "speech_only", "speech", 2, False, False),
+    (["meld_emotion"], "speech_only", "text", 4, False, False),
+    (["meld_emotion_greek"], "text_only", "text", 4, False, False),
+    (["meld_emotion_swap"], "speech_only", "text", 2, False, False),
+    (["sqa"], "speech_only", "text", 2, False, False),
+    (["sqa"], "speech_only", "speech", 2, False, False),
+    (["sqa"], "text_only", "text", 1, False, False),
+    (["sqa"], "speech_and_text", "text", 0, False, False),
+    (["vp_nel"], "speech_only", "text", 3, False, False),
+    (["voxceleb", "hvb", "voxpopuli"], "speech_only", "text", 5, False, False),
+    (["voxceleb", "hvb", "voxpopuli"], "speech_only", "text", 2, False, True),
+    (["hvb", "voxceleb"], "text_only", "text", 1, True, True),
+]
+DATASET_SIZES = dict(n_items=4, n_lookup=5, n_fewshot=5, audio_seconds=(0.05, 0.15), seed=11)
+
+
+def g10_dataset_items():
+    """Items and batches of the reference's own dataset pipeline (DatasetFactory → InferenceDataset / MultiTaskInferenceDataset →
+    SalmonProcessor) over seeded on-disk datasets written by this repo's ``write_synthetic_hf_datasets``."""
+    import random
+    import shutil
+    import tempfile
+    sys.path.insert(0, REF)
+    from transformers import WhisperFeatureExtractor
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_synthetic_hf_datasets
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType as MyDT
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    import data.master_config as mc
+    import data.voxceleb_config as c1, data.hvb_config as c2, data.voxpopuli_config as c3, data.meld_emotion_config as c4
+    from data.dataset_factory import DatasetFactory
+    from data.model_processors import SalmonProcessor
+    from utils.data_utils import load_dataset, clear_dataset_cache
+    root = tempfile.mkdtemp(prefix="icl_golden_ds_")
+    try:
+        all_types = sorted({t for case in DATASET_CASES for t in case[0]})
+        write_synthetic_hf_datasets(root, [MyDT(t) for t in all_types], **DATASET_SIZES)
+        seen = set()
+        for cfg in (list(mc.DATASET_CONFIGS.values()) + c1.VOXCELEB_SWAP_CONFIGS + c2.HVB_SWAP_CONFIGS + c3.VOXPOPULI_SWAP_CONFIGS
+                    + c4.MELD_EMOTION_SWAP_CONFIGS):
+            for d in (cfg.paths, cfg.audio_lookup_paths):
+                if d is not None and id(d) not in seen:
+                    seen.add(id(d))
+                    for k in list(d):
+                        d[k] = os.path.join(root, os.path.basename(d[k].rstrip("/")))
+        proc = SalmonProcessor.__new__(SalmonProcessor)
+        proc.tokenizer, proc.max_length, proc.batch_counter = ByteTokenizer(260), 128, 0
+        proc.processor = WhisperFeatureExtractor()
+        out = []
+        for tasks, input_mode, fewshot_mode, k, balance, interleave in DATASET_CASES:
+            clear_dataset_cache()
+            dts = [mc.DatasetType(t) for t in tasks]
+            random.seed(5)
+            np.random.seed(6)
+            rows = {dt: load_dataset(dt, split="test") for dt in dts}
+            ds = DatasetFactory.create_dataset(dataset_type=dts, dataset=rows, processor=proc, is_training=False,
+                                               input_mode=input_mode, fewshot_mode=fewshot_mode, num_examples=k,
+                                               random_examples=False, model_type="salmonn", randomize_swap=False,
+                                               balance_datasets=balance, interleave=interleave)
+            items = [ds[i] for i in range(len(ds))]
+
+            def L(x):
+                return None if x is None else int(len(x))
+
+            rec = []
+            for it in items:
+                r = {"prompt": it["prompt"], "completion": it["completion"], "text": it["text"],
+                     "dataset_type": it["dataset_type"].value, "num_examples": int(it["num_examples"])}
+                if "question" in it:
+                    r.update({"question": it["question"], "unique_id": it["unique_id"],
+                              "question_wav_length": int(it["question_wav_length"]),
+                              "document_wav_length": int(it["document_wav_length"]),
+                              "example_lengths": [[int(e["question"]["wav_length"]), int(e["document"]["wav_length"])]
+                                                  for e in it["examples_speech"]],
+                              "wav_sum": None if it["question_raw_wav"] is None else float(it["question_raw_wav"].double().sum()
+                                                                                           + it["document_raw_wav"].double().sum())})
+                else:
+                    r.update({"wav_length": int(it["wav_length"]),
+                              "example_lengths": [int(e["wav_length"]) for e in it["examples_speech"]],
+                              "wav_sum": None if it["raw_wav"] is None else float(it["raw_wav"].double().sum())})
+                rec.append(r)
+            batch = proc.collate_batch(items[:3])
+            shapes = {key: (list(v.shape) if hasattr(v, "shape") else len(v)) for key, v in batch.items()
+                      if "spectrogram" not in key}
+            out.append({"tasks": tasks, "input_mode": input_mode, "fewshot_mode": fewshot_mode, "num_examples": k,
+                        "balance": balance, "interleave": interleave, "len": len(ds), "items": rec, "batch3": shapes})
+        with open(os.path.join(HERE, "dataset_items.json"), "w") as f:
+            json.dump({"sizes": {k: (list(v) if isinstance(v, tuple) else v) for k, v in DATASET_SIZES.items()}, "cases": out}, f, indent=0)
+        print(f"dataset_items.json: {len(out)} cases, {os.path.getsize(os.path.join(HERE, 'dataset_items.json')) / 1024:.1f} KiB")
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 if __name__ == "__main__":
     g1_logmel()
     g2_whisper()
@@ -346,3 +494,4 @@ if __name__ == "__main__":
     g7_qwen2_audio()
     g8_clean_prediction()
     g9_metrics()
+    g10_dataset_items()

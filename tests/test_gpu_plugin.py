@@ -123,3 +123,90 @@ def test_cli_end_to_end(tmp_path):
     assert any(f.endswith("_results.json") for f in files) and any(f.endswith("_metrics.json") for f in files)
     res = json.load(open(tmp_path / [f for f in files if f.endswith("_results.json")][0]))
     assert len(res) == 6 and set(res[0]) == {"text", "true_label", "predicted_label (cleaned)", "predicted_label", "dataset_type"}
+
+
+def _sqa_batch(model, root, fewshot_mode, num_examples, bs=2):
+    import random
+    from icl_speech_text_llm_amd.data.dataset_factory import DatasetFactory
+    from icl_speech_text_llm_amd.data.model_processors import get_processor
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_synthetic_hf_datasets
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType
+    from icl_speech_text_llm_amd.utils.data_utils import clear_dataset_cache, load_dataset
+    write_synthetic_hf_datasets(str(root), [DatasetType.SQA], n_items=3, n_lookup=4, audio_seconds=(1.0, 2.5), seed=3)
+    clear_dataset_cache()
+    proc = get_processor("salmonn", model.input_processor, model.llama_tokenizer)
+    random.seed(9)
+    ds = DatasetFactory.create_dataset(DatasetType.SQA, load_dataset(DatasetType.SQA, "test"), proc, input_mode="speech_only",
+                                       fewshot_mode=fewshot_mode, num_examples=num_examples)
+    return proc.collate_batch([ds[i] for i in range(bs)])
+
+
+def test_sqa_two_audio_batches_match_oracle(model, tmp_path):
+    """f4: SQA (question + document audio for the query and for every speech exemplar) through get_speech_embeddings →
+    custom_prompt_wrap → forward/generate; interleave order document→question (custom_salmon.py:206-241) against the
+    oracle run on the same wrapped sequence."""
+    from icl_speech_text_llm_amd.data import task_configs as tc
+    from icl_speech_text_llm_amd.models.custom_salmon import interleave_plan_sqa, split_prompt
+    from oracle import models as om
+    try:
+        for few, k in (("text", 2), ("speech", 1)):
+            b = _sqa_batch(model, tmp_path, few, k, bs=1)
+            assert "question_raw_wav" in b and "document_raw_wav" in b and b["dataset_type"][0].value == "sqa"
+            sp, sa, ee, ea = model.get_speech_embeddings(dict(b))
+            H = model.cfg.llama.hidden
+            assert isinstance(sp, tuple) and sp[0].shape == (1, 88, H) and sp[1].shape == (1, 88, H)
+            assert (ee is None) == (few == "text")
+            if ee is not None:
+                assert len(ee[0]) == 1 and isinstance(ee[0][0], tuple) and ee[0][0][1].shape == (88, H)
+            wrapped, atts = model.custom_prompt_wrap(sp, sa, b["prompt"], b["num_examples"], ee, ea)
+            # rebuild the sequence by hand: text parts through the embedding table, audios in document→question order
+            llm = _oracle_llama(model, om.bf16_round)
+            n_ex = int(b["num_examples"][0])
+            parts = split_prompt(b["prompt"][0], n_ex, ee is not None, is_sqa=True)
+            pieces = []
+            for kind, i in interleave_plan_sqa(len(parts), n_ex, None if ee is None else len(ee[0]), True):
+                if kind == "text":
+                    ids = model.llama_tokenizer.encode(parts[i], add_special_tokens=False)
+                    if ids:
+                        pieces.append(llm.embed(torch.tensor(ids, dtype=torch.long)))
+                else:
+                    src = {"speech_q": lambda: sp[0][0], "speech_d": lambda: sp[1][0], "example_q": lambda: ee[0][i][0],
+                           "example_d": lambda: ee[0][i][1]}[kind]()
+                    pieces.append(src.float().cpu())
+            want = torch.cat(pieces, 0)
+            assert wrapped.shape == (1, want.shape[0], H)
+            assert float((wrapped[0].float().cpu() - want).abs().max()) < 1e-6
+            n_audio = 2 + 2 * (0 if ee is None else len(ee[0]))
+            assert want.shape[0] == sum(len(model.llama_tokenizer.encode(p, add_special_tokens=False)) for p in parts) + 88 * n_audio
+            out = model.forward({k_: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k_, v in b.items()})
+            tgt = model.llama_tokenizer(b["completion"], padding="longest", return_tensors="pt", add_special_tokens=False)
+            full = torch.cat([want, llm.embed(tgt.input_ids[0])], 0)[None]
+            ref_logits, ref_loss = llm.forward(full, out["labels"].cpu())
+            rel = float((out["logits"].cpu() - ref_logits).norm() / ref_logits.norm())
+            assert rel < 6e-3, rel
+            text = model.generate_output({k_: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k_, v in b.items()})
+            assert len(text) == 1 and isinstance(text[0], str)
+        b2 = _sqa_batch(model, tmp_path, "speech", 2, bs=2)       # batch of 2, two speech exemplars each: 12 audios, one chain
+        assert len(model.generate_output({k_: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k_, v in b2.items()})) == 2
+    finally:
+        tc.set_dataset_root(None)
+
+
+def test_cli_on_dataset_folders(tmp_path):
+    """f2 end to end: --dataset_root with on-disk HF folders (greek + swap + multi-label tasks, round-robin interleave)."""
+    from icl_speech_text_llm_amd.data import task_configs as tc
+    from icl_speech_text_llm_amd.inference.inference import main
+    try:
+        rc = main(["--peft_model_path", "", "--run_name", "d", "--dataset_type", "voxceleb_greek-hvb_swap-voxpopuli", "--arch", "tiny",
+                   "--dataset_root", str(tmp_path / "data"), "--write_synthetic_datasets", "--synthetic_items", "3",
+                   "--num_examples", "2", "--interleave", "True", "--batch_size", "3", "--num_workers", "0",
+                   "--results_dir", str(tmp_path / "out"), "--device", "cuda"])
+        assert rc == 0
+        files = sorted(os.listdir(tmp_path / "out"))
+        res = json.load(open(tmp_path / "out" / [f for f in files if f.endswith("_results.json")][0]))
+        assert len(res) == 9 and [r["dataset_type"] for r in res[:3]] == ["voxceleb_greek", "hvb_swap", "voxpopuli"]
+        assert all(r["true_label"] in ("alpha", "beta", "gamma") for r in res if r["dataset_type"] == "voxceleb_greek")
+        met = json.load(open(tmp_path / "out" / [f for f in files if f.endswith("_metrics.json")][0]))
+        assert set(met) == {"voxceleb_greek", "hvb_swap", "voxpopuli"} and "macro_f1" in met["voxpopuli"]
+    finally:
+        tc.set_dataset_root(None)

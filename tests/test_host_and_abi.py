@@ -1,5 +1,6 @@
 """CPU: the C-ABI library loads and exports every symbol include/icl_hip.h declares (no compute without a GPU);
 argument validation fails loudly; host-side plugin logic; world_size-2 gloo data-parallel sharding."""
+import json
 import os
 import re
 import subprocess
@@ -147,3 +148,59 @@ def test_data_parallel_sharding_gloo_world2(tmp_path):
     assert a["n"] == b["n"] == 10
     assert a["texts"] == b["texts"] and a["preds"] == b["preds"]
     assert any(f.endswith("_metrics.json") for f in os.listdir(multi))
+
+
+def test_dataset_pipeline_matches_reference_items(tmp_path):
+    """f2: rows of on-disk HF datasets → few-shot prompt / completion / audio, for every task family, input mode and
+    multi-task ordering, against items captured from the reference's own DatasetFactory + InferenceDataset +
+    SalmonProcessor over the same seeded folders (tests/golden/make_golden.py::g10_dataset_items)."""
+    import random
+    import numpy as np
+    from icl_speech_text_llm_amd.data import task_configs as tc
+    from icl_speech_text_llm_amd.data.dataset_factory import DatasetFactory
+    from icl_speech_text_llm_amd.data.model_processors import SalmonProcessor
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_synthetic_hf_datasets
+    from icl_speech_text_llm_amd.utils.data_utils import clear_dataset_cache, load_dataset
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dataset_items.json")))
+    sizes = dict(g["sizes"], audio_seconds=tuple(g["sizes"]["audio_seconds"]))
+    all_types = sorted({t for c in g["cases"] for t in c["tasks"]})
+    try:
+        write_synthetic_hf_datasets(str(tmp_path), [tc.DatasetType(t) for t in all_types], **sizes)
+        proc = SalmonProcessor(ByteTokenizer(260))
+        assert len(g["cases"]) >= 25
+        for case in g["cases"]:
+            clear_dataset_cache()
+            dts = [tc.DatasetType(t) for t in case["tasks"]]
+            random.seed(5)
+            np.random.seed(6)
+            rows = {dt: load_dataset(dt, split="test") for dt in dts}
+            ds = DatasetFactory.create_dataset(dataset_type=dts, dataset=rows, processor=proc, is_training=False,
+                                               input_mode=case["input_mode"], fewshot_mode=case["fewshot_mode"],
+                                               num_examples=case["num_examples"], random_examples=False,
+                                               randomize_swap=False, balance_datasets=case["balance"],
+                                               interleave=case["interleave"])
+            assert len(ds) == case["len"], case["tasks"]
+            items = [ds[i] for i in range(len(ds))]
+            for it, want in zip(items, case["items"]):
+                tag = (case["tasks"], case["input_mode"], case["fewshot_mode"])
+                assert it["prompt"] == want["prompt"], tag
+                assert it["completion"] == want["completion"] and it["text"] == want["text"], tag
+                assert it["dataset_type"].value == want["dataset_type"] and int(it["num_examples"]) == want["num_examples"], tag
+                if "question" in want:
+                    assert it["question"] == want["question"] and it["unique_id"] == want["unique_id"]
+                    assert [it["question_wav_length"], it["document_wav_length"]] == [want["question_wav_length"], want["document_wav_length"]]
+                    assert [[e["question"]["wav_length"], e["document"]["wav_length"]] for e in it["examples_speech"]] == want["example_lengths"]
+                    s = None if it["question_raw_wav"] is None else float(it["question_raw_wav"].double().sum() + it["document_raw_wav"].double().sum())
+                else:
+                    assert it["wav_length"] == want["wav_length"], tag
+                    assert [e["wav_length"] for e in it["examples_speech"]] == want["example_lengths"], tag
+                    s = None if it["raw_wav"] is None else float(it["raw_wav"].double().sum())
+                assert (s is None) == (want["wav_sum"] is None) and (s is None or abs(s - want["wav_sum"]) < 1e-9), tag
+            batch = proc.collate_batch(items[:3])
+            for key, shape in case["batch3"].items():          # every tensor the reference batches (spectrograms aside: GPU K1)
+                got = batch[key]
+                assert (list(got.shape) if hasattr(got, "shape") else len(got)) == shape, (key, case["tasks"])
+    finally:
+        tc.set_dataset_root(None)
+        clear_dataset_cache()

@@ -72,10 +72,11 @@ def test_llama_forward_loss_and_generate_match_hf():
     assert g0.tolist() == a["gen_eos0"].tolist() and g0.shape == (1, 1)
 
 
-@pytest.mark.parametrize("case", ["text_only", "speech_text_ex", "speech_speech_ex"])
+@pytest.mark.parametrize("case", ["text_only", "speech_text_ex", "speech_speech_ex", "sqa_speech_text_ex",
+                                  "sqa_speech_speech_ex", "sqa_speechtext_zero"])
 def test_prompt_wrap_labels_logits_generate_match_reference_glue(case):
     """Our host-side prompt logic + the Llama oracle reproduce what the REFERENCE's CustomSALMONN computed."""
-    from icl_speech_text_llm_amd.models.custom_salmon import build_labels, interleave_plan, split_prompt
+    from icl_speech_text_llm_amd.models.custom_salmon import build_labels, interleave_plan, interleave_plan_sqa, split_prompt
     from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
     from oracle import models as om
     meta = json.load(open(os.path.join(G, "glue_cases.json")))[case]
@@ -86,11 +87,18 @@ def test_prompt_wrap_labels_logits_generate_match_reference_glue(case):
     speech = torch.from_numpy(a["speech"]) if "speech" in a else None
     examples = torch.from_numpy(a["examples"]) if "examples" in a else None
     n_ex = meta["num_examples"]
-    parts = split_prompt(meta["prompt"], n_ex, examples is not None)
+    sqa = meta.get("sqa", False)
+    if sqa:
+        speech = {"speech_q": torch.from_numpy(a["speech_q"]), "speech_d": torch.from_numpy(a["speech_d"])}
+        examples = {"example_q": torch.from_numpy(a["examples_q"]), "example_d": torch.from_numpy(a["examples_d"])} if "examples_q" in a else None
+    parts = split_prompt(meta["prompt"], n_ex, examples is not None, is_sqa=sqa)
     pieces = []
-    for kind, i in interleave_plan(len(parts), n_ex, len(examples) if examples is not None else None, speech is not None):
+    n_emb = None if examples is None else (len(examples["example_q"]) if sqa else len(examples))
+    for kind, i in (interleave_plan_sqa if sqa else interleave_plan)(len(parts), n_ex, n_emb, speech is not None):
         if kind == "text":
             pieces.append(llm.embed(torch.tensor(tok.encode(parts[i], add_special_tokens=False), dtype=torch.long)))
+        elif sqa:
+            pieces.append(speech[kind] if kind.startswith("speech") else examples[kind][i])
         else:
             pieces.append(speech if kind == "speech" else examples[i])
     wrapped = torch.cat(pieces, 0)
@@ -139,11 +147,19 @@ def test_format_prompt_matches_reference_formatter():
     gold = json.load(open(os.path.join(G, "format_prompt.json")))
     proc = SalmonProcessor(tokenizer=None)
     ex = [{"text": f"example sentence number {i} about things", "label": ["positive", "negative", "neutral"][i % 3]} for i in range(5)]
+    sqa_ex = [{"question": f"what about item {i}", "document": f"the document number {i} says things", "completion": f"{i}.5 {i + 2}.25"}
+              for i in range(2)]
+    assert sum(k.startswith("sqa|") for k in gold) == 7
     for key, want in gold.items():
         dt, mode, few = key.split("|")
         tmpl = get_dataset_config(DatasetType(dt)).prompt_template
-        got = proc.format_prompt(tmpl, "query text", None if few == "zero" else ex[:3], input_mode=mode,
-                                 fewshot_mode="text" if few == "zero" else few)
+        if dt == "sqa":
+            got = proc.format_prompt(tmpl, "document text", None if few == "zero" else sqa_ex, input_mode=mode,
+                                     fewshot_mode="text" if few == "zero" else few, dataset_type=DatasetType.SQA,
+                                     question="the question")
+        else:
+            got = proc.format_prompt(tmpl, "query text", None if few == "zero" else ex[:3], input_mode=mode,
+                                     fewshot_mode="text" if few == "zero" else few)
         assert got == want, key
 
 
