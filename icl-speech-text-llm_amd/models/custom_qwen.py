@@ -173,7 +173,7 @@ class CustomQwen(BaseModel):
     def __init__(self, model_path: str = "Qwen/Qwen2-Audio-7B-Instruct", lora: bool = True, low_resource: bool = True,
                  lora_rank: int = 8, lora_alpha: int = 32, lora_dropout: float = 0.05, prompt_template: str = "",
                  max_txt_len: int = 512, ckpt_path: Optional[str] = None, device=None, use_fp16: bool = True,
-                 arch=None, tokenizer=None, seed: int = 0, **ignored):
+                 arch=None, tokenizer=None, seed: int = 0, generation_config: Optional[Dict[str, Any]] = None, **ignored):
         super().__init__(device=device, use_fp16=use_fp16)
         if ignored:
             logger.info("CustomQwen: ignoring unknown kwargs %s", sorted(ignored))
@@ -194,6 +194,7 @@ class CustomQwen(BaseModel):
                 tokenizer = QwenSpecialTokenizer(cfg.llm.vocab, cfg.audio_token_id, cfg.llm.eos_id, cfg.llm.pad_id)
         self.input_processor = QwenHostProcessor(self, tokenizer)
         self.prompt_template, self.max_txt_len, self.lora = prompt_template, max_txt_len, lora
+        self.generation_config = dict(generation_config or {})
         self.batch_counter = 0
 
     @property
@@ -256,8 +257,16 @@ class CustomQwen(BaseModel):
 
     def generate_output(self, batch: Dict[str, Any]) -> List[str]:
         rows, segs, speech, _, _ = self._rows_and_audio(batch)
+        # The reference calls generate(max_new_tokens=10) and inherits every other knob from the checkpoint's
+        # generation_config.json (custom_qwen.py:227-233), which is not reachable here: greedy by default; ``generation_config``
+        # (constructor kwarg or batch keys) switches on the sampled tail with the same kernel as the SALMONN path.
+        g = {**self.generation_config, **{k: batch[k] for k in ("do_sample", "temperature", "top_p", "top_k", "repetition_penalty",
+                                                                   "generator") if k in batch}}
         res = self.runtime.generate(segs, speech, max_new_tokens=int(batch.get("max_new_tokens", 10)),
-                                    eos_id=self.cfg.llm.eos_id, pad_id=self.cfg.llm.pad_id)
+                                    eos_id=self.cfg.llm.eos_id, pad_id=self.cfg.llm.pad_id,
+                                    do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),
+                                    top_p=float(g.get("top_p", 1.0)), top_k=int(g.get("top_k", 50)),
+                                    repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"))
         self.batch_counter += 1
         return self.input_processor.batch_decode(res.tokens, skip_special_tokens=True, clean_up_tokenization_spaces=False)
 

@@ -454,13 +454,20 @@ class CustomSALMONN(BaseModel):
 
     def generate_output(self, samples: Dict[str, Any]) -> List[str]:
         t0 = time.time()
-        if samples.get("num_beams", 1) != 1 or samples.get("do_sample", False):
-            raise NotImplementedError("the MI355X path implements greedy search only (num_beams=1, do_sample=False)")
+        if samples.get("num_beams", 1) != 1:
+            raise NotImplementedError("the MI355X path implements greedy search and sampling, not beam search (num_beams=1)")
         speech_embeds, _, example_embeds, _ = self.get_speech_embeddings(samples)
         num_examples = samples.get("num_examples", torch.zeros(len(samples["prompt"]), dtype=torch.long))
         segs, speech = self._segments(speech_embeds, samples["prompt"], num_examples, example_embeds)
+        # generation knobs and their defaults as the reference reads them (:708-715); min_length / length_penalty have no
+        # effect on this path (min_length is a no-op with inputs_embeds, length_penalty only acts on beams)
         res = self.runtime.generate(segs, speech, max_new_tokens=int(samples.get("max_new_tokens", 10)),
-                                    eos_id=self.llama_tokenizer.eos_token_id, pad_id=self.llama_tokenizer.pad_token_id)
+                                    eos_id=self.llama_tokenizer.eos_token_id, pad_id=self.llama_tokenizer.pad_token_id,
+                                    do_sample=bool(samples.get("do_sample", False)),
+                                    temperature=float(samples.get("temperature", 0.8)), top_p=float(samples.get("top_p", 0.9)),
+                                    top_k=int(samples.get("top_k", 50)),
+                                    repetition_penalty=float(samples.get("repetition_penalty", 1.0)),
+                                    generator=samples.get("generator"))
         preds = self.llama_tokenizer.batch_decode(res.tokens, skip_special_tokens=True)
         self.batch_counter += 1
         logger.debug("Generation took %.3f s", time.time() - t0)

@@ -71,6 +71,9 @@ _SIGNATURES = {
                                             c_int32, c_int32, c_void_p]),
     "icl_argmax_eos": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                c_int32, c_int32, c_void_p, c_void_p]),
+    "icl_sample_eos": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int32,
+                               c_float, c_float, c_int32, c_float, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                               c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "icl_logmel_whisper": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
                                    c_void_p, c_int64, c_void_p, c_void_p]),
     "icl_spec_to_xt": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
@@ -272,6 +275,25 @@ def argmax_eos(logits, eos_id: int, pad_id: int, finished, out_tokens, step: int
                                          logits.shape[1] if V is None else V, eos_id, pad_id, finished.data_ptr(),
                                          out_tokens.data_ptr(), out_tokens.stride(0), step, next_ids.data_ptr(),
                                          _stream()), "icl_argmax_eos")
+
+
+def sample_eos(logits, work, uniforms, eos_id: int, pad_id: int, finished, out_tokens, step: int, next_ids, *,
+               temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.0, V=None,
+               debug=None):
+    """Sampled decode tail: tokens generated so far (``out_tokens[:, :step]``) feed the repetition penalty; ``uniforms`` f32 [B]
+    are the draws; ``debug`` = (ids int32 [B,cap], probs f32 [B,cap], count int32 [B]) receives the kept distribution."""
+    _require_gpu(logits, work, uniforms, finished, out_tokens, next_ids)
+    assert logits.dtype == torch.float32 and work.dtype == torch.float32 and uniforms.dtype == torch.float32
+    V = logits.shape[1] if V is None else V
+    dbg = (None, None, None, 0)
+    if debug is not None:
+        _require_gpu(*debug)
+        dbg = (debug[0].data_ptr(), debug[1].data_ptr(), debug[2].data_ptr(), debug[0].shape[1])
+    _check(load_library().icl_sample_eos(logits.data_ptr(), logits.stride(0), logits.shape[0], V, work.data_ptr(),
+                                         work.stride(0), out_tokens.data_ptr(), out_tokens.stride(0), step,
+                                         repetition_penalty, temperature, top_k, top_p, uniforms.data_ptr(), eos_id, pad_id,
+                                         finished.data_ptr(), out_tokens.data_ptr(), out_tokens.stride(0), step,
+                                         next_ids.data_ptr(), dbg[0], dbg[1], dbg[2], dbg[3], _stream()), "icl_sample_eos")
 
 
 def logmel_whisper(wav, wav_lens, mel_filters, n_mel: int, spec, xt, workspace):

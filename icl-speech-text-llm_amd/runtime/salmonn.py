@@ -105,11 +105,19 @@ class CausalLMRuntimeMixin:
 
     def generate(self, prompts, speech: Optional[torch.Tensor], max_new_tokens: int = 10, eos_id: Optional[int] = None,
                  pad_id: Optional[int] = None, suppress_eos: bool = False, want_first_logits: bool = False,
-                 cache_len_multiple: int = 64) -> GenerateResult:
+                 cache_len_multiple: int = 64, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
+                 top_k: int = 50, repetition_penalty: float = 1.0, generator: Optional[torch.Generator] = None,
+                 sample_debug=None) -> GenerateResult:
         """Greedy search with HF ``generate(inputs_embeds=…)`` semantics (models/custom_salmon.py:704-720): returns only
         the new tokens; a row that has emitted EOS is filled with pad; the width is that of the longest row
         (``min_length`` is a no-op with inputs_embeds).  All steps are enqueued without a host sync; the
-        early-stop width is applied on the host afterwards (identical output, no per-token round trip)."""
+        early-stop width is applied on the host afterwards (identical output, no per-token round trip).
+
+        ``do_sample=True`` switches the tail to the sampling kernel (HF's sample mode: repetition penalty → temperature →
+        top-k → top-p → draw; ``temperature`` / ``top_p`` / ``top_k`` are ignored otherwise, as in HF); a repetition penalty
+        ≠ 1 in greedy mode runs the same kernel with ``top_k = 1``.  The draws are uniforms from ``generator`` (a device
+        generator; default: torch's global CUDA generator): reproducible for a seed, not bit-identical to
+        ``torch.multinomial``."""
         c, ws, dev = self.lm_cfg, self.ws, self.device
         eos = c.eos_id if eos_id is None else eos_id
         pad = c.pad_id if pad_id is None else pad_id
@@ -136,7 +144,26 @@ class CausalLMRuntimeMixin:
         finished.zero_()
         toks = ws.get("gen_tokens", (Bn, max_new_tokens), I32)
         nxt = ws.get("gen_next", (Bn,), I32)
-        B.argmax_eos(logits, eos, pad, finished, toks, 0, nxt)
+        sampled = do_sample or repetition_penalty != 1.0
+        if sampled:
+            knobs = ((float(temperature), int(top_k), float(top_p)) if do_sample else (1.0, 1, 1.0)) + (float(repetition_penalty),)
+            uni = ws.get("gen_uniform", (max_new_tokens, Bn), F32)
+            if do_sample:
+                uni.uniform_(0.0, 1.0, generator=generator)
+            else:
+                uni.zero_()
+            work = ws.get("gen_sample_work", (Bn, logits.shape[1]), F32)
+
+            def tail(lg, step):
+                B.sample_eos(lg, work, uni[step], eos, pad, finished, toks, step, nxt, temperature=knobs[0], top_k=knobs[1],
+                             top_p=knobs[2], repetition_penalty=knobs[3], V=c.vocab,
+                             debug=sample_debug if step == 0 else None)
+        else:
+            knobs = None
+
+            def tail(lg, step):
+                B.argmax_eos(lg, eos, pad, finished, toks, step, nxt, V=c.vocab)
+        tail(logits, 0)
         if max_new_tokens > 1:
             steps = max_new_tokens - 1
             # positions of the fed token / cache length after its append, per step: static buffers (graph-replayable)
@@ -150,12 +177,12 @@ class CausalLMRuntimeMixin:
             def decode_loop():
                 for t in range(steps):
                     lg = self.llama.decode_step(ws, cache, nxt, pos_all[t], len_all[t], sid)
-                    B.argmax_eos(lg, eos, pad, finished, toks, t + 1, nxt)
+                    tail(lg, t + 1)
 
             # The decode loop is launch-bound at small batch (~17 kernels x layers x steps): after one eager pass that
             # sizes every workspace buffer, it is captured ONCE per (batch, cache length, steps, eos, pad) into a HIP
             # graph and replayed — all pointers are workspace-stable and nothing inside synchronises or allocates.
-            gkey = (Bn, max_len, steps, eos, pad)
+            gkey = (Bn, max_len, steps, eos, pad, knobs)
             graph = self._graphs.get(gkey) if self.use_graphs else None
             if graph is not None:
                 graph.replay()

@@ -187,6 +187,25 @@ int icl_argmax_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, int32
                    int32_t pad_id, int32_t* finished, int32_t* out_tokens, int32_t out_stride,
                    int32_t step, int32_t* next_ids, void* stream);
 
+/* ---- K11 (sampled): repetition penalty -> temperature -> top-k -> top-p -> inverse-CDF draw + EOS/pad bookkeeping ----
+ * Per sequence b: scores = logits[b] with every token in prev_tokens[b][0..n_prev) rescaled (x<0 ? x*penalty : x/penalty),
+ * all divided by temperature; candidates = scores >= the top_k-th largest score (ties kept); probabilities = softmax over
+ * the candidates sorted by (score desc, token asc); candidate j is dropped when the mass of candidates j.. is <= 1-top_p
+ * (the largest always stays); the token is the first kept candidate whose running mass exceeds uniforms[b] * kept mass.
+ * Then exactly icl_argmax_eos's bookkeeping.  work f32 [B][ldw>=V] is scratch; top_k in [1,1024]; greedy search with a
+ * repetition penalty is top_k = 1.  Optional debug outputs (NULL to skip): the kept tokens, their renormalised
+ * probabilities and their count, dbg_cap entries per sequence.
+ * Replaces HF generate(do_sample=True, temperature, top_p, repetition_penalty) as called at models/custom_salmon.py:705-721
+ * (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper [generation-config default 50],
+ * TopPLogitsWarper, softmax, multinomial).
+ */
+int icl_sample_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, float* work, int64_t ldw,
+                   const int32_t* prev_tokens, int32_t prev_stride, int32_t n_prev, float repetition_penalty,
+                   float temperature, int32_t top_k, float top_p, const float* uniforms, int32_t eos_id,
+                   int32_t pad_id, int32_t* finished, int32_t* out_tokens, int32_t out_stride, int32_t step,
+                   int32_t* next_ids, int32_t* dbg_ids, float* dbg_probs, int32_t* dbg_count, int32_t dbg_cap,
+                   void* stream);
+
 /* ---- K1: Whisper log-mel (f64 STFT, f32 out) ---------------------------------------------
  * wav f32 [n_audio][wav_ld] with valid lengths wav_lens (device int32; samples past the length
  * or past 480000 are treated as zero), -> spec f32 [n_audio][80][3000] (n_mel x 3000) and,

@@ -27,6 +27,8 @@ and is compared with a tight tolerance, with ``rnd=None`` it is the reference's 
 from __future__ import annotations
 
 import math
+
+import numpy as np
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -404,3 +406,79 @@ class LlamaOracle:
             lg = self.logits(self.forward_hidden(e, p, cache))[:, 0]
         ids = torch.stack(out, dim=1)
         return (ids, first) if return_first_logits else ids
+
+    def generate_sampled(self, inputs_embeds: Tensor, max_new_tokens: int, eos_id: int, pad_id: int, uniforms: Tensor,
+                         do_sample: bool = True, temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0,
+                         repetition_penalty: float = 1.0):
+        """HF sample mode with inputs_embeds only (models/custom_salmon.py:705-721): per step the scores go through
+        ``sample_filter`` and the token is the inverse-CDF draw ``sample_pick(probs, uniforms[step, b])``.  With
+        ``do_sample=False`` it is greedy search under the repetition penalty (temperature / top-k / top-p ignored, as in HF)."""
+        B, T, _ = inputs_embeds.shape
+        cache: list = []
+        h = self.forward_hidden(inputs_embeds.float(), torch.arange(T)[None].expand(B, T), cache)
+        lg = self.logits(h[:, -1:])[:, 0]
+        finished = torch.zeros(B, dtype=torch.bool)
+        out: list = []
+        kept = []
+        for step in range(max_new_tokens):
+            toks = []
+            for b in range(B):
+                prev = [int(o[b]) for o in out]
+                if do_sample:
+                    ids, probs = sample_filter(lg[b].numpy(), prev, repetition_penalty, temperature, top_k, top_p)
+                    toks.append(int(ids[sample_pick(probs, float(uniforms[step, b]))]))
+                else:
+                    ids, probs = sample_filter(lg[b].numpy(), prev, repetition_penalty, 1.0, 1, 1.0)
+                    toks.append(int(ids[0]))
+                if step == 0:
+                    kept.append((ids, probs))
+            tok = torch.where(finished, torch.full((B,), pad_id), torch.tensor(toks))
+            out.append(tok)
+            finished = finished | (tok == eos_id)
+            if bool(finished.all()) or step == max_new_tokens - 1:
+                break
+            lg = self.logits(self.forward_hidden(self.embed(tok)[:, None], torch.full((B, 1), T + step), cache))[:, 0]
+        return torch.stack(out, dim=1), kept
+
+
+def sample_filter(logits, prev_tokens, repetition_penalty: float, temperature: float, top_k: int, top_p: float):
+    """The distribution HF samples from, restated from the logits processors the reference's ``generate`` call builds
+    (transformers/generation/logits_process.py: RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper,
+    TopPLogitsWarper) in float32: returns (token ids, probabilities) of the kept tokens ordered by (score descending,
+    token ascending) — the order the HIP kernel draws in."""
+    x = np.asarray(logits, dtype=np.float32).copy()
+    raw = x.copy()
+    if repetition_penalty != 1.0:
+        pen = np.float32(repetition_penalty)
+        for t in set(int(t) for t in prev_tokens):
+            if 0 <= t < x.shape[0]:
+                x[t] = raw[t] * pen if raw[t] < 0 else raw[t] / pen
+    x = x / np.float32(temperature)
+    kth = np.sort(x)[::-1][min(top_k, x.shape[0]) - 1]
+    cand = np.nonzero(x >= kth)[0]
+    order = np.lexsort((cand, -x[cand].astype(np.float64)))
+    cand = cand[order]
+    e = np.exp((x[cand] - x[cand[0]]).astype(np.float32)).astype(np.float32)
+    p = e / np.float32(e.sum(dtype=np.float32))
+    keep = len(cand)
+    if top_p < 1.0:
+        keep, tail = 1, np.float32(0.0)
+        for j in range(len(cand) - 1, 0, -1):
+            tail = np.float32(tail + p[j])
+            if tail > np.float32(1.0) - np.float32(top_p):
+                keep = j + 1
+                break
+    total = np.float32(0.0)
+    for j in range(keep):
+        total = np.float32(total + p[j])
+    return cand[:keep].astype(np.int64), (p[:keep] / total).astype(np.float32)
+
+
+def sample_pick(probs, u: float) -> int:
+    """First index whose running probability mass exceeds ``u`` (inverse CDF over the kept, renormalised distribution)."""
+    acc = 0.0
+    for j, pj in enumerate(probs):
+        acc += float(pj)
+        if acc > u:
+            return j
+    return len(probs) - 1

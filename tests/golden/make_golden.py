@@ -379,6 +379,34 @@ def g9_metrics():
     print(f"metrics.json: {len(cases)} + {len(nel)} cases, {os.path.getsize(os.path.join(HERE, 'metrics.json')) / 1024:.1f} KiB")
 
 
+def g11_sampling():
+    """The distribution HF's sample mode draws from, for the knobs the reference passes (custom_salmon.py:705-721)."""
+    from transformers.generation.logits_process import (LogitsProcessorList, RepetitionPenaltyLogitsProcessor,
+                                                        TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper)
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    cases = [(0.8, 50, 0.9, 1.0), (0.8, 50, 0.9, 1.3), (1.0, 5, 0.5, 1.0), (0.3, 50, 0.95, 2.0), (1.5, 200, 0.99, 1.1),
+             (0.8, 1, 0.9, 1.2), (0.7, 20, 1.0, 1.0)]
+    for i, (temp, k, p, pen) in enumerate(cases):
+        V = 777
+        logits = torch.randn(3, V, generator=g) * 3.0
+        logits[1, 100:110] = logits[1].max() + 0.25           # a tie at the top-k boundary and at the top
+        prev = torch.randint(0, V, (3, 6), generator=g)
+        prev[2, :3] = logits[2].topk(3).indices               # penalised tokens inside the nucleus
+        procs = LogitsProcessorList()
+        if pen != 1.0:
+            procs.append(RepetitionPenaltyLogitsProcessor(penalty=pen))
+        if temp != 1.0:
+            procs.append(TemperatureLogitsWarper(temp))
+        procs.append(TopKLogitsWarper(top_k=k, min_tokens_to_keep=1))
+        if p < 1.0:
+            procs.append(TopPLogitsWarper(top_p=p, min_tokens_to_keep=1))
+        probs = torch.softmax(procs(prev, logits.clone()), dim=-1)
+        out[f"logits_{i}"], out[f"prev_{i}"], out[f"probs_{i}"] = logits, prev, probs
+        out[f"knobs_{i}"] = np.array([temp, k, p, pen], dtype=np.float64)
+    save("sampling.npz", **out)
+
+
 DATASET_CASES = [   # (tasks, input_mode, fewshot_mode, num_examples, balance, interleave)
     (["voxceleb"], "speech_only", "text", 5, False, False),
     (["voxceleb"], "speech_only", "speech", 3, False, False),
@@ -495,3 +523,4 @@ if __name__ == "__main__":
     g8_clean_prediction()
     g9_metrics()
     g10_dataset_items()
+    g11_sampling()

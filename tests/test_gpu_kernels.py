@@ -459,3 +459,71 @@ def test_gemm_skinny_swiglu(B, M):
     B.gemm(a, w, out, swiglu=True, tile=4)
     ref = torch.nn.functional.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
     assert _relerr(out, ref) < 4e-3
+
+
+def _sample_case(logits, prev, step, temp, k, p, pen, u, eos=-1, pad=0, finished=None):
+    from icl_speech_text_llm_amd.runtime import binding as Bd
+    Bn, V = logits.shape
+    dev = "cuda"
+    lg = logits.to(dev).contiguous()
+    toks = torch.zeros(Bn, 16, dtype=torch.int32, device=dev)
+    if step:
+        toks[:, :step] = prev[:, :step].to(torch.int32).to(dev)
+    fin = torch.zeros(Bn, dtype=torch.int32, device=dev) if finished is None else finished.to(torch.int32).to(dev)
+    nxt = torch.zeros(Bn, dtype=torch.int32, device=dev)
+    work = torch.empty(Bn, V, dtype=torch.float32, device=dev)
+    dbg = (torch.full((Bn, 1024), -1, dtype=torch.int32, device=dev), torch.zeros(Bn, 1024, device=dev),
+           torch.zeros(Bn, dtype=torch.int32, device=dev))
+    Bd.sample_eos(lg, work, u.to(dev), eos, pad, fin, toks, step, nxt, temperature=temp, top_k=k, top_p=p,
+                  repetition_penalty=pen, debug=dbg)
+    torch.cuda.synchronize()
+    return toks.cpu(), nxt.cpu(), fin.cpu(), [d.cpu() for d in dbg]
+
+
+def test_sample_eos_matches_oracle_and_hf_golden():
+    """Sampled decode tail (csrc/sampling.hip) vs the oracle's restatement of HF's logits processors: kept tokens in draw order
+    (exact), probabilities (1e-6), the inverse-CDF pick for given uniforms (exact away from CDF boundaries), ties at the
+    top-k boundary, repetition penalty on tokens inside the nucleus, full Llama (32001) and Qwen (156032) vocabularies."""
+    import os
+    from oracle import models as om
+    g = torch.Generator().manual_seed(5)
+    for V, temp, k, p, pen in ((32001, 0.8, 50, 0.9, 1.0), (32001, 0.8, 50, 0.9, 1.3), (156032, 0.7, 20, 0.5, 1.1),
+                               (777, 1.0, 5, 0.5, 1.0), (260, 1.5, 200, 0.99, 1.2), (32001, 1.0, 1000, 1.0, 1.0),
+                               (32001, 0.6, 1, 1.0, 1.5)):
+        Bn, step = 5, 6
+        logits = torch.randn(Bn, V, generator=g) * 3.0
+        logits[1, 100:110] = logits[1].max() + 0.25
+        prev = torch.randint(0, V, (Bn, 16), generator=g)
+        prev[2, :3] = logits[2].topk(3).indices
+        u = torch.rand(Bn, generator=g)
+        toks, nxt, fin, (ids, probs, cnt) = _sample_case(logits, prev, step, temp, k, p, pen, u)
+        for b in range(Bn):
+            oi, op = om.sample_filter(logits[b].numpy(), prev[b, :step].tolist(), pen, temp, k, p)
+            n = int(cnt[b])
+            assert n == len(oi), (V, b, n, len(oi))
+            assert ids[b, :n].tolist() == oi.tolist(), (V, b)
+            assert float((probs[b, :n] - torch.from_numpy(op)).abs().max()) < 1e-6, (V, b)
+            cdf = np.cumsum(op.astype(np.float64))
+            if np.abs(cdf - float(u[b])).min() > 1e-5:
+                assert int(nxt[b]) == int(oi[om.sample_pick(op, float(u[b]))]), (V, b)
+            assert int(toks[b, step]) == int(nxt[b]) and toks[b, :step].tolist() == prev[b, :step].tolist()
+    # the HF golden (tests/golden/sampling.npz) through the kernel
+    a = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampling.npz"))
+    for i in range(7):
+        temp, k, p, pen = a[f"knobs_{i}"].tolist()
+        logits, prev = torch.from_numpy(a[f"logits_{i}"]), torch.from_numpy(a[f"prev_{i}"])
+        prev16 = torch.zeros(3, 16, dtype=torch.long)
+        prev16[:, :6] = prev
+        _, _, _, (ids, probs, cnt) = _sample_case(logits, prev16, 6, temp, int(k), p, pen, torch.rand(3, generator=g))
+        for b in range(3):
+            want = a[f"probs_{i}"][b]
+            kept = np.nonzero(want > 0)[0]
+            n = int(cnt[b])
+            assert n == len(kept), (i, b)
+            assert np.abs(np.sort(probs[b, :n].numpy()) - np.sort(want[kept])).max() < 2e-6, (i, b)
+    # bookkeeping: a finished row emits pad whatever the draw; a drawn EOS finishes the row
+    logits = torch.randn(2, 300, generator=g)
+    top = int(logits[1].argmax())
+    toks, nxt, fin, _ = _sample_case(logits, torch.zeros(2, 16, dtype=torch.long), 0, 1.0, 1, 1.0, 1.0, torch.zeros(2),
+                                     eos=top, pad=7, finished=torch.tensor([1, 0]))
+    assert nxt.tolist() == [7, top] and fin.tolist() == [1, 1]

