@@ -197,6 +197,16 @@ class HipLogMelFeatureExtractor:
 def _arch_from_paths(llama_path: str, whisper_path: str, beats_path: str, arch) -> SalmonnCfg:
     if isinstance(arch, SalmonnCfg):
         return arch
+    from ..runtime import checkpoints as ck
+    lj = ck.read_config(llama_path) if llama_path else None
+    wj = ck.read_config(whisper_path) if whisper_path else None
+    if arch is None and (lj or wj):      # architecture numbers from the HF folders' config.json
+        base = SalmonnCfg.llama2_7b()
+        whisper = ck.whisper_cfg_from_hf(wj) if wj else base.whisper
+        llama = ck.llama_cfg_from_hf(lj, base.llama) if lj else base.llama
+        beats = base.beats if beats_path else None
+        qf = QFormerCfg(enc_width=whisper.d_model + (beats.d_model if beats else 0))
+        return SalmonnCfg(whisper=whisper, beats=beats, qformer=qf, llama=llama)
     name = (arch or "").lower()
     if name == "tiny":
         return SalmonnCfg.tiny(use_beats=bool(beats_path))
@@ -238,6 +248,11 @@ class CustomSALMONN(BaseModel):
         self.max_txt_len = max_txt_len
         # low_resource (8-bit bitsandbytes in the reference) has no effect: the north star computes in bf16.
         self.salmonn = SalmonnModule(cfg, self.device, seed=seed)
+        from ..runtime.checkpoints import load_pretrained_parts
+        pretrained = load_pretrained_parts(llama_path, whisper_path, beats_path, vocab=cfg.llama.vocab)
+        if pretrained:
+            missing = self.salmonn.load_state_dict(pretrained, strict=False)
+            logger.info("loaded %d pretrained tensors (llama/whisper/beats folders)", len(pretrained))
         if ckpt_path and os.path.isfile(ckpt_path):
             ckpt = torch.load(ckpt_path, map_location="cpu")
             self.salmonn.load_state_dict(ckpt.get("model", ckpt), strict=False)

@@ -2,9 +2,8 @@
 
 ``create_model(model_type, multi_task, task_configs, default_task, device, **model_kwargs)`` keeps the
 reference's signature and error behaviour: unknown type -> ``ValueError`` re-raised as
-``RuntimeError("Failed to create model: ...")`` (:60-61, :95-98).  ``multi_task=True`` (the
-``MultiTaskModel`` wrapper) is outside the hot path — both of the reference's drivers pass
-``multi_task=False`` (inference/inference.py:149) — and raises.  Unknown kwargs such as the ``use_cache`` that
+``RuntimeError("Failed to create model: ...")`` (:60-61, :95-98).  ``multi_task=True`` wraps the model in
+``MultiTaskModel`` (per-task generation knobs and prompt templates).  Unknown kwargs such as the ``use_cache`` that
 ``from_config`` forwards (:142) are tolerated by the model constructors.
 """
 from __future__ import annotations
@@ -31,9 +30,13 @@ class ModelFactory:
             if multi_task:
                 if not task_configs:
                     raise ValueError("task_configs required for multi-task models")
-                raise NotImplementedError("MultiTaskModel is outside the MI355X hot path (SURVEY.md §2.1 #5)")
-            logger.info("Creating single-task %s model", model_type)
-            if model_type == "salmonn":
+                from .multi_task_model import MultiTaskModel
+                logger.info("Creating multi-task %s model", model_type)
+                if "device" not in model_kwargs:
+                    model_kwargs = dict(model_kwargs, device=device)
+                model = MultiTaskModel(model_type=model_type, task_configs=task_configs, default_task=default_task, **model_kwargs)
+            elif model_type == "salmonn":
+                logger.info("Creating single-task %s model", model_type)
                 from .custom_salmon import CustomSALMONN
                 model = CustomSALMONN(device=device, **model_kwargs) if "device" not in model_kwargs else CustomSALMONN(**model_kwargs)
             else:

@@ -286,4 +286,4 @@ def test_generate_sampled_and_penalised_greedy(env):
             if step + 1 < len(got):
                 lg = ob.logits(ob.forward_hidden(ob.embed(torch.tensor([tok]))[:, None], torch.full((1, 1), T + step), cache))[0, 0]
         ids, _ = ob.generate_sampled(emb, 3, -1, cfg.llama.pad_id, None, do_sample=False, repetition_penalty=1.5)
-        assert ids.shape == (1, 3) and int(ids[0, 0]) == got[0] or True
+        assert ids.shape == (1, 3)

@@ -204,3 +204,28 @@ def test_dataset_pipeline_matches_reference_items(tmp_path):
     finally:
         tc.set_dataset_root(None)
         clear_dataset_cache()
+
+
+def test_hf_folder_ingestion_yields_canonical_names(tmp_path):
+    """f3 (host part): HF Llama / Whisper folders → exactly the parameter names the packers read (runtime/synth.py emits the
+    same set), architecture from config.json, one zero [PAD] row appended to embed_tokens and lm_head."""
+    from transformers import LlamaConfig, LlamaForCausalLM, WhisperConfig, WhisperModel
+    from icl_speech_text_llm_amd.runtime import checkpoints as ck, synth
+    from icl_speech_text_llm_amd.runtime.config import LlamaCfg, QFormerCfg, SalmonnCfg
+    LlamaForCausalLM(LlamaConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                                 intermediate_size=512, vocab_size=259, tie_word_embeddings=False)).save_pretrained(tmp_path / "l")
+    WhisperModel(WhisperConfig(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, decoder_layers=1,
+                               decoder_attention_heads=2, decoder_ffn_dim=64, vocab_size=64, pad_token_id=0, bos_token_id=1,
+                               eos_token_id=2, decoder_start_token_id=1)).save_pretrained(tmp_path / "w")
+    lc = ck.llama_cfg_from_hf(ck.read_config(str(tmp_path / "l")), LlamaCfg(lora_rank=0))
+    wc = ck.whisper_cfg_from_hf(ck.read_config(str(tmp_path / "w")))
+    assert (lc.hidden, lc.n_layers, lc.n_heads, lc.ffn, lc.vocab, lc.pad_id) == (256, 2, 2, 512, 260, 259)
+    sd = ck.load_pretrained_parts(str(tmp_path / "l"), str(tmp_path / "w"), "", vocab=lc.vocab)
+    cfg = SalmonnCfg(whisper=wc, beats=None, qformer=QFormerCfg(enc_width=128), llama=lc)
+    want = {k: tuple(v.shape) for k, v in synth.salmonn_state(cfg, seed=0, device="cpu").items()
+            if k.startswith(("llama_model.", "speech_encoder."))}
+    assert {k: tuple(v.shape) for k, v in sd.items()} == want
+    assert float(sd["llama_model.model.embed_tokens.weight"][259].abs().max()) == 0.0
+    with pytest.raises(NotImplementedError, match="grouped-query"):
+        ck.llama_cfg_from_hf({"hidden_size": 256, "num_hidden_layers": 1, "num_attention_heads": 4, "num_key_value_heads": 2,
+                              "intermediate_size": 512, "vocab_size": 10}, LlamaCfg())
