@@ -217,6 +217,8 @@ class QwenProcessor:
 
     def format_prompt(self, template: str, text: str, examples: Optional[List[Dict]] = None,
                       input_mode: str = "speech_only", fewshot_mode: str = "text", dataset_type=None, **kw) -> str:
+        if _is_sqa(dataset_type):
+            return self._format_sqa_prompt(template, text, examples, input_mode, fewshot_mode, **kw)
         user: List[Dict[str, Any]] = []
         if examples:
             user.append({"type": "text", "text": "Here are few examples to learn from:\n"})
@@ -234,11 +236,48 @@ class QwenProcessor:
         conv = [{"role": "system", "content": template}, {"role": "user", "content": user}]
         return self.processor.apply_chat_template(conv, add_generation_prompt=True, tokenize=False)
 
+    def _format_sqa_prompt(self, template, text, examples, input_mode, fewshot_mode, **kw) -> str:
+        """SQA conversation (:240-316): per exemplar question audio, document audio, answer (speech few-shot) or three text
+        items; then the query as question audio [+ text], document audio [+ text].  The reference reads the exemplar's
+        ``answer`` key although the dataset fills ``completion`` (multi_task_dataset.py:262-270) — kept: answers render empty."""
+        question = kw.get("question", "")
+        user: List[Dict[str, Any]] = []
+        if examples:
+            user.append({"type": "text", "text": "Here are few examples to learn from:\n"})
+            for i, ex in enumerate(examples):
+                answer = ex.get("answer", "")
+                if fewshot_mode == "speech":
+                    user += [{"type": "audio", "audio_url": f"question_{i}"}, {"type": "audio", "audio_url": f"document_{i}"},
+                             {"type": "text", "text": f"Answer: {answer}\n"}]
+                else:
+                    user += [{"type": "text", "text": f"Question: {ex.get('question', '')}\n"},
+                             {"type": "text", "text": f"Document: {ex.get('document', '')}\n"},
+                             {"type": "text", "text": f"Answer: {answer}\n"}]
+        user.append({"type": "text", "text": "\nNow analyze this input:\n"})
+        if input_mode in ("speech_and_text", "speech_only"):
+            user.append({"type": "audio", "audio_url": "question"})
+            if input_mode == "speech_and_text" and question:
+                user.append({"type": "text", "text": f"Question text: {question}\n"})
+            user.append({"type": "audio", "audio_url": "document"})
+            if input_mode == "speech_and_text" and text:
+                user.append({"type": "text", "text": f"Document text: {text}"})
+        else:
+            user += [{"type": "text", "text": f"Question: {question}\n"}, {"type": "text", "text": f"Document: {text}"}]
+        conv = [{"role": "system", "content": template}, {"role": "user", "content": user}]
+        return self.processor.apply_chat_template(conv, add_generation_prompt=True, tokenize=False)
+
     def process_inputs(self, data: Dict[str, Any], is_training: bool = False) -> Dict[str, Any]:
         text = data.get("prompt", "")
-        audios = list(data.get("examples_audio") or [])
-        if data.get("audio") is not None:
-            audios.append(data["audio"])
+        if _is_sqa(data.get("dataset_type")):          # audio order (:85-100): exemplars (question, document)…, then the query's
+            audios = []
+            for ex in (data.get("examples_audio") or []):
+                audios += [a for a in (ex.get("question_audio"), ex.get("document_audio")) if a is not None]
+            main = data.get("audio") or {}
+            audios += [a for a in (main.get("question_audio"), main.get("document_audio")) if a is not None]
+        else:
+            audios = list(data.get("examples_audio") or [])
+            if data.get("audio") is not None:
+                audios.append(data["audio"])
         full = text + (f"{data.get('completion', '')}{self.processor.tokenizer.eos_token}" if is_training else "")
         prompt_len = self.processor(text=text, audios=audios, return_tensors="pt", sampling_rate=16000).input_ids.shape[1]
         enc = self.processor(text=full, audios=audios, return_tensors="pt", sampling_rate=16000)

@@ -407,6 +407,34 @@ def g11_sampling():
     save("sampling.npz", **out)
 
 
+class ConversationDump:
+    """Stand-in for the HF AutoProcessor inside the reference's QwenProcessor: renders the conversation structure verbatim."""
+
+    def apply_chat_template(self, conversation, add_generation_prompt=True, tokenize=False):
+        return json.dumps({"conversation": conversation, "add_generation_prompt": add_generation_prompt}, sort_keys=True)
+
+
+def g12_qwen_prompts():
+    """Conversation assembly of the reference's QwenProcessor (default + SQA) for every input / few-shot mode."""
+    sys.path.insert(0, REF)
+    from data.model_processors import QwenProcessor as RefQwen
+    from data.master_config import DatasetType as RefDT
+    proc = RefQwen(ConversationDump())
+    ex = [{"text": f"example sentence {i}", "label": ["positive", "negative"][i % 2]} for i in range(3)]
+    sqa_ex = [{"question": f"what about item {i}", "document": f"document {i} says things", "completion": f"{i}.5 {i + 2}.25",
+               "answer": f"ans{i}"} for i in range(2)]
+    out = {}
+    for mode in ("speech_only", "text_only", "speech_and_text"):
+        for few, exs in (("text", ex), ("speech", ex), ("zero", None)):
+            fm = "text" if few == "zero" else few
+            out[f"default|{mode}|{few}"] = proc.format_prompt("SYSTEM TEMPLATE", "query text", exs, mode, fm, RefDT.HVB)
+            out[f"sqa|{mode}|{few}"] = proc.format_prompt("SYSTEM TEMPLATE", "document text", None if few == "zero" else sqa_ex,
+                                                          mode, fm, RefDT.SQA, question="the question")
+    with open(os.path.join(HERE, "qwen_prompts.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print(f"qwen_prompts.json: {len(out)} prompts")
+
+
 DATASET_CASES = [   # (tasks, input_mode, fewshot_mode, num_examples, balance, interleave)
     (["voxceleb"], "speech_only", "text", 5, False, False),
     (["voxceleb"], "speech_only", "speech", 3, False, False),
@@ -524,3 +552,4 @@ if __name__ == "__main__":
     g9_metrics()
     g10_dataset_items()
     g11_sampling()
+    g12_qwen_prompts()

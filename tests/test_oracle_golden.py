@@ -248,3 +248,30 @@ def test_sampling_distribution_matches_hf_logits_processors():
             assert np.abs(probs[[ids.tolist().index(t) for t in both]] - want[both]).max() < 2e-6, (i, b)
             assert all(probs[j] >= probs[j + 1] - 1e-9 for j in range(len(probs) - 1))
             assert om.sample_pick(probs, 0.0) == 0 and om.sample_pick(probs, 0.999999) == len(probs) - 1
+
+
+def test_qwen_conversation_assembly_matches_reference():
+    """QwenProcessor.format_prompt (default and SQA): same conversation items in the same order as the reference's
+    (data/model_processors.py:240-383), rendered through a processor stand-in that dumps the structure."""
+    from icl_speech_text_llm_amd.data.model_processors import QwenProcessor
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType
+
+    class Dump:
+        def apply_chat_template(self, conversation, add_generation_prompt=True, tokenize=False):
+            return json.dumps({"conversation": conversation, "add_generation_prompt": add_generation_prompt}, sort_keys=True)
+
+    gold = json.load(open(os.path.join(G, "qwen_prompts.json")))
+    proc = QwenProcessor(Dump())
+    ex = [{"text": f"example sentence {i}", "label": ["positive", "negative"][i % 2]} for i in range(3)]
+    sqa_ex = [{"question": f"what about item {i}", "document": f"document {i} says things", "completion": f"{i}.5 {i + 2}.25",
+               "answer": f"ans{i}"} for i in range(2)]
+    assert len(gold) == 18
+    for key, want in gold.items():
+        kind, mode, few = key.split("|")
+        fm = "text" if few == "zero" else few
+        if kind == "sqa":
+            got = proc.format_prompt("SYSTEM TEMPLATE", "document text", None if few == "zero" else sqa_ex, mode, fm,
+                                     DatasetType.SQA, question="the question")
+        else:
+            got = proc.format_prompt("SYSTEM TEMPLATE", "query text", None if few == "zero" else ex, mode, fm, DatasetType.HVB)
+        assert got == want, key
