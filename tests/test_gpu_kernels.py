@@ -50,6 +50,46 @@ def test_gemm_plain(B, M, N, K, tile):
     assert _relerr(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("K", [256, 512, 1280])
+def test_gemm_many_tiles_all_epilogues(B, K):
+    """256x256 kernel over a grid of 616 tiles (2-3 per CU), every epilogue; the all-interior launch is bit-compared with a
+    launch whose extra row adds an edge row-tile (a row's arithmetic must not depend on how the grid is cut)."""
+    M, N = 256 * 44, 256 * 14                     # 616 tiles
+    a, w = _rand_bf16(M + 1, K, seed=11, scale=0.5), _rand_bf16(N, K, seed=12, scale=0.1)
+    bias = torch.randn(N, device=DEV)
+    res32 = torch.randn(M + 1, N, device=DEV)
+    res16 = _rand_bf16(M + 1, N, seed=13)
+    base = a[:M].float() @ w.float().t()
+
+    def both(out_dtype, n_out=N, **kw):
+        outs = []
+        for rows in (M, M + 1):
+            out = torch.full((rows, n_out), float("nan"), dtype=out_dtype, device=DEV)
+            r = kw.get("residual")
+            B.gemm(a[:rows], w, out, tile=3, **{**kw, **({"residual": r[:rows]} if r is not None else {})})
+            outs.append(out[:M])
+        assert torch.equal(outs[0], outs[1]), kw.keys()
+        return outs[0]
+
+    out = both(torch.float32)
+    assert (out - base).abs().max().item() <= 1e-3 * math.sqrt(K) and _relerr(out, base) < 1e-5
+    out = both(torch.bfloat16, bias=bias, gelu=True)
+    assert _relerr(out, torch.nn.functional.gelu(base + bias)) < 4e-3
+    out = both(torch.float32, bias=bias, residual=res32)
+    assert (out - (base + bias + res32[:M])).abs().max().item() <= 2e-3
+    out = both(torch.bfloat16, residual=res16)
+    assert _relerr(out, base + res16[:M].float()) < 4e-3
+    out = both(torch.float32, bias=bias, gelu=True, residual=res32)
+    assert (out - (torch.nn.functional.gelu(base + bias) + res32[:M])).abs().max().item() <= 2e-3
+    out = both(torch.bfloat16, n_out=N // 2, swiglu=True)
+    g = base.view(M, N // 32, 2, 16)
+    assert _relerr(out, (torch.nn.functional.silu(g[:, :, 0]) * g[:, :, 1]).reshape(M, N // 2)) < 4e-3
+    # in-place residual stream (the way the engines call it)
+    stream = res32[:M].clone()
+    B.gemm(a[:M], w, stream, bias=bias, residual=stream, tile=3)
+    assert (stream - (base + bias + res32[:M])).abs().max().item() <= 2e-3
+
+
 def test_gemm_identity_asymmetric(B):
     # A = I with an asymmetric W catches a transposed C write (guide §3)
     K = 128
