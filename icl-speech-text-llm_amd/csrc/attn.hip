@@ -9,9 +9,12 @@
 //     of k-step s (guide §3 "An accumulator tile as the next MFMA's operand"); the matching,
 //     k-permuted V^T A-operand comes from two ds_read_b64_tr_b16 transposed reads of the
 //     row-major V tile.  The per-query rescale is then a per-lane scalar.
-//   * K/V tiles are register-staged (global -> VGPR issued before the compute of the current
-//     tile, ds_write into the OTHER LDS buffer after it: T14; one barrier per tile), rows padded (K: +16 B, V: +64 B) so that both the
-//     ds_read_b128 K-fragment reads and the transposed V reads are bank-conflict free.
+//   * K/V tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB per wave-instruction, no VGPR round trip and no
+//     ds_write): tile t+1 is issued at the top of iteration t into the OTHER buffer, one vmcnt(0) + barrier per tile.
+//     The DMA destination is lane-linear, so rows are unpadded and bank conflicts are removed by swizzling on the SOURCE
+//     side: LDS slot s of row r holds global 16-B chunk s ^ f(r); K: f = (r>>1)&7 (D=64) / r&15 (D=128) makes the
+//     ds_read_b128 fragment reads conflict-free, V: f = ((r>>1)&1)<<2 (D=64) / (r&3)<<2 (D=128) does it for the
+//     transposed ds_read_b64_tr_b16 reads.
 // Variable-length packing (cu_seqlens), causal masking, a key-padding length per sequence and the
 // BEATs gated relative-position bias are handled in the score stage.
 #include "common.h"
@@ -28,30 +31,61 @@ struct AttnParams {
   const float* rel_bias;
   const float* rel_gate;
   int64_t ldq, ldk, ldv, ldo;
-  int n_heads, rel_span;
+  int n_heads, rel_span, n_qblocks;
   float scale_log2e;
 };
 
 constexpr float NEG_BIG = -1.0e30f;
+
+// fmaxf on MFMA outputs makes hipcc prepend a canonicalising v_max per operand (3 instructions per max of 2); the scores
+// are never signalling NaNs, so take the raw 3-input maximum: 16 instructions for the 32 scores of a tile instead of 57.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max2_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max32_raw(const f32x16& a, const f32x16& b) {
+  float m = max3_raw(a[0], a[1], a[2]);
+#pragma unroll
+  for (int r = 3; r + 1 < 16; r += 2) m = max3_raw(m, a[r], a[r + 1]);
+  m = max3_raw(m, a[15], b[0]);
+#pragma unroll
+  for (int r = 1; r + 1 < 16; r += 2) m = max3_raw(m, b[r], b[r + 1]);
+  return max2_raw(m, b[15]);
+}
 constexpr float LOG2E = 1.4426950408889634f;
 
 template <int D, bool CAUSAL, bool BIAS>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
-  constexpr int KSTR = D * 2 + 16;  // bytes per K row in LDS
-  constexpr int VSTR = D * 2 + 64;  // bytes per V row in LDS
+__global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
+  constexpr int ROWB = D * 2;       // bytes per K / V row in LDS (unpadded: LDS-DMA writes lane-linear)
   constexpr int KS = D / 16;        // QK^T k-steps
   constexpr int DB = D / 32;        // output d-blocks
   constexpr int CPR = D / 8;        // 16-B chunks per row
-  constexpr int NCH = 64 * CPR / 256;  // staging chunks per thread per tensor
-  constexpr int BUF = 64 * KSTR + 64 * VSTR;   // one K tile + one V tile
-  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];   // double-buffered: ONE barrier per KV tile
+  constexpr int NCH = 64 * CPR / 256;  // LDS-DMA wave-instructions per wave per tensor (1 KiB each)
+  constexpr int RPI = 64 / CPR;        // rows per DMA instruction
+  constexpr int BUF = 2 * 64 * ROWB;   // one K tile + one V tile
+  constexpr int NBUF = D == 64 ? 3 : 2;   // ring depth: tiles are staged NBUF-1 iterations ahead (D=128: 2 x 32 KiB keeps 2 blocks/CU)
+  constexpr int AHEAD = NBUF - 1;
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF];   // ONE barrier per KV tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hh = lane >> 5;
-  const int seq = blockIdx.z, head = blockIdx.y;
+  // XCD-aware decode of a 1-D grid: consecutive block ids are dispatched round-robin over the 8 XCDs, each with its own L2.
+  // Block b -> work item (b % 8) * ceil(n/8)-chunk + b / 8 (bijective), work items ordered q-block fastest: all q-blocks of
+  // one (sequence, head) run on ONE XCD back to back, so its K/V (re-read by every q-block) is fetched into one L2 once.
+  const int n_blocks = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = n_blocks >> 3, r8 = n_blocks & 7;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int qblk = item % p.n_qblocks;
+  const int head = (item / p.n_qblocks) % p.n_heads, seq = item / (p.n_qblocks * p.n_heads);
   const int row0 = p.cu[seq];
   const int len = p.cu[seq + 1] - row0;
-  const int qb = blockIdx.x * 128;
+  const int qb = qblk * 128;
   if (qb >= len) return;
   int kvlen = len;
   if (p.kv_lens) kvlen = min(max(p.kv_lens[seq], 1), len);
@@ -76,28 +110,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     bias_row = p.rel_bias + (int64_t)head * (2 * p.rel_span - 1) + (p.rel_span - 1);
   }
 
-  // ---- staging -------------------------------------------------------------------------------------
-  u32x4 kreg[NCH], vreg[NCH];
-  auto load_tile = [&](int t) {
+  // ---- staging: LDS-DMA with source-side swizzle --------------------------------------------------------
+  // DMA instruction j = wave * NCH + i of a tensor covers rows RPI*j .. RPI*j + RPI-1; lane l lands in row RPI*j + l / CPR,
+  // slot l % CPR, and fetches global chunk slot ^ f(row).  Row pointers advance by one tile per iteration; only a tile that
+  // crosses the end of the sequence takes the clamped form (rows past the end are masked, the read must stay in bounds).
+  auto f_k = [](int row) { return D == 64 ? (row >> 1) & 7 : row & 15; };
+  auto f_v = [](int row) { return D == 64 ? ((row >> 1) & 1) << 2 : (row & 3) << 2; };
+  const unsigned short* kptr[NCH];
+  const unsigned short* vptr[NCH];
+  int srow[NCH], kch[NCH], vch[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int j = wave * NCH + i;
+    srow[i] = RPI * j + lane / CPR;
+    kch[i] = (lane % CPR) ^ f_k(srow[i]);
+    vch[i] = (lane % CPR) ^ f_v(srow[i]);
+    kptr[i] = p.K + (int64_t)(row0 + srow[i]) * p.ldk + head * D + kch[i] * 8;
+    vptr[i] = p.V + (int64_t)(row0 + srow[i]) * p.ldv + head * D + vch[i] * 8;
+  }
+  const int64_t kstep = 64 * p.ldk, vstep = 64 * p.ldv;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto stage_tile = [&](int t, int buf) {
     const int k0 = t * 64;
+    char* k_w = lds + buf * BUF + wave * NCH * 1024;
+    char* v_w = k_w + 64 * ROWB;
+    if (k0 + 64 <= len) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * 256;
-      const int r = c / CPR, cc = c - r * CPR;
-      const int64_t grow = row0 + min(k0 + r, len - 1);
-      kreg[i] = *(const u32x4*)(p.K + grow * p.ldk + head * D + cc * 8);
-      vreg[i] = *(const u32x4*)(p.V + grow * p.ldv + head * D + cc * 8);
-    }
-  };
-  auto write_tile = [&](int buf) {
-    char* k_w = lds + buf * BUF;
-    char* v_w = k_w + 64 * KSTR;
+      for (int i = 0; i < NCH; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(kptr[i] + (int64_t)t * kstep), (lptr_t)(k_w + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vptr[i] + (int64_t)t * vstep), (lptr_t)(v_w + i * 1024), 16, 0, 0);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * 256;
-      const int r = c / CPR, cc = c - r * CPR;
-      *(u32x4*)(k_w + r * KSTR + cc * 16) = kreg[i];
-      *(u32x4*)(v_w + r * VSTR + cc * 16) = vreg[i];
+      for (int i = 0; i < NCH; ++i) {
+        const int64_t grow = row0 + min(k0 + srow[i], len - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.K + grow * p.ldk + head * D + kch[i] * 8), (lptr_t)(k_w + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.V + grow * p.ldv + head * D + vch[i] * 8), (lptr_t)(v_w + i * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -108,18 +158,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;
 
-  // transposed-read lane address pieces (bytes): row (i>>2), column 4*(i&3) of the 16-lane group
-  const int tr_lane_off = ((lane & 15) >> 2) * VSTR + ((((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
+  // K fragment reads: row kb*32 + ql, logical chunk 2*ks + hh -> physical chunk ^ f_k(row) (f_k(row + 32) = f_k(row))
+  int k_off[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_off[ks] = ql * ROWB + (((2 * ks + hh) ^ f_k(ql)) << 4);
+  // transposed V reads: lane i of a 16-lane group reads row (i>>2) [+4*hh, +8 for the second read], logical chunk
+  // 4*d + 2*((lane>>4)&1) + ((lane&3)>>1), half (lane&1); the rows' f_v depends only on (i>>2)
+  int tr_off[DB];
+  {
+    const int q = (lane & 15) >> 2;
+    const int c2 = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+      tr_off[d] = (4 * hh + q) * ROWB + (((4 * d + c2) ^ f_v(q)) << 4) + (lane & 1) * 8;
+  }
 
-  load_tile(0);
-  write_tile(0);
+  // counted waits: the AHEAD-1 youngest tiles (2*NCH LDS-DMA instructions each) stay in flight across the barrier
+  auto wait_oldest_tile = [&]() {
+    if constexpr (AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (NCH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  };
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a) stage_tile(min(a, n_tiles - 1), a);
+  wait_oldest_tile();
   __syncthreads();
+  int cur = 0;            // ring slot of tile t
 
   for (int t = 0; t < n_tiles; ++t) {
-    if (t + 1 < n_tiles) load_tile(t + 1);
+    // unconditional (the last iteration stages its own tile again, into the idle buffer): a conditional issue makes hipcc's
+    // waitcnt pass merge the two paths pessimistically
+    int nxt = cur + AHEAD;
+    if (nxt >= NBUF) nxt -= NBUF;
+    stage_tile(min(t + AHEAD, n_tiles - 1), nxt);   // that slot held tile t-1: last read in iteration t-1 (barrier passed)
     const int k0 = t * 64;
-    const char* k_lds = lds + (t & 1) * BUF;
-    const char* v_lds = k_lds + 64 * KSTR;
+    const char* k_lds = lds + cur * BUF;
+    const char* v_lds = k_lds + 64 * ROWB;
     // wave-uniform: does this wave have any visible key in this tile?
     const bool active = !CAUSAL || (k0 <= qw + 31);
     if (active) {
@@ -129,10 +203,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
-        const char* kp = k_lds + (kb * 32 + ql) * KSTR + hh * 16;
+        const char* kp = k_lds + kb * 32 * ROWB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 kf = *(const bf16x8*)(kp + ks * 32);
+          const bf16x8 kf = *(const bf16x8*)(kp + k_off[ks]);
           s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kb], 0, 0, 0);
         }
       }
@@ -142,11 +216,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       float psum = 0.f, alpha;
       bf16x8 pf[2][2];
       if (!BIAS && !need_mask) {
-        float tmax = fmaxf(s_acc[0][0], s_acc[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s_acc[0][r], s_acc[1][r]));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;
-        const float m_new = fmaxf(m_run, tmax);
+        float tmax = max32_raw(s_acc[0], s_acc[1]);
+        tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;   // scale > 0: max commutes with the scaling
+        const float m_new = max2_raw(m_run, tmax);
         alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
 #pragma unroll
@@ -175,11 +247,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
               v = ok ? v : NEG_BIG;
             }
             s_acc[kb][r] = v;
-            tmax = fmaxf(tmax, v);
           }
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
+        tmax = max32_raw(s_acc[0], s_acc[1]);
+        tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = max2_raw(m_run, tmax);
         alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
 #pragma unroll
@@ -194,10 +266,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
       }
       l_run = l_run * alpha + psum;
+      // the running maximum settles after the first tiles: skip the rescale when no query of the wave moved (x * 1.0f is exact)
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-      for (int d = 0; d < DB; ++d)
+        for (int d = 0; d < DB; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+      }
       // ---- O^T += V^T P^T -----------------------------------------------------------------------------
 #pragma unroll
       for (int d = 0; d < DB; ++d) {
@@ -205,9 +280,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            const char* vp = v_lds + (kb * 32 + 16 * s + 4 * hh) * VSTR + d * 64 + tr_lane_off;
+            const char* vp = v_lds + (kb * 32 + 16 * s) * ROWB + tr_off[d];
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * VSTR));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * ROWB));
             typedef __attribute__((ext_vector_type(8))) short s16x8;
             const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
@@ -216,9 +291,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
       }
     }
-    // the other buffer was last read in iteration t-1, and every wave has passed the barrier that ended it
-    if (t + 1 < n_tiles) write_tile((t + 1) & 1);
+    wait_oldest_tile();   // this wave's share of tile t+1 has landed
     __syncthreads();
+    cur = cur + 1 == NBUF ? 0 : cur + 1;
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l -------------------------------------------------------------
@@ -241,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 
 template <int D>
 int launch_attn(const AttnParams& p, const icl_attn_args* a, hipStream_t stream) {
-  dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seqs);
+  dim3 grid(((a->max_seqlen + 127) / 128) * a->n_heads * a->n_seqs, 1, 1);
   const bool bias = a->rel_bias != nullptr;
   if (a->causal) {
     if (bias)
@@ -285,6 +360,7 @@ extern "C" int icl_attn_fwd_bf16(const icl_attn_args* a, void* stream) {
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
   p.n_heads = a->n_heads;
   p.rel_span = a->rel_span;
+  p.n_qblocks = (a->max_seqlen + 127) / 128;
   p.scale_log2e = a->scale * LOG2E;
   return a->head_dim == 64 ? launch_attn<64>(p, a, (hipStream_t)stream) : launch_attn<128>(p, a, (hipStream_t)stream);
 }
