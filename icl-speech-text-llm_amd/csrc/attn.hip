@@ -61,7 +61,12 @@ __device__ __forceinline__ float max32_raw(const f32x16& a, const f32x16& b) {
 constexpr float LOG2E = 1.4426950408889634f;
 
 template <int D, bool CAUSAL, bool BIAS>
-__global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
+  // 32-query blocks per wave: at D = 64 two of them share every K and V fragment read, every staged byte and every
+  // barrier (the loop is issue-bound, not MFMA-bound); the gated-bias variant keeps one (its 32 table gathers per tile and
+  // lane want the third wave per SIMD more than the sharing: 3.2 ms vs 2.4 ms per BEATs layer at 128 clips)
+  constexpr int QB = (D == 64 && !BIAS) ? 2 : 1;
+  constexpr int BQ = 128 * QB;      // queries per workgroup
   constexpr int ROWB = D * 2;       // bytes per K / V row in LDS (unpadded: LDS-DMA writes lane-linear)
   constexpr int KS = D / 16;        // QK^T k-steps
   constexpr int DB = D / 32;        // output d-blocks
@@ -85,30 +90,29 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   const int head = (item / p.n_qblocks) % p.n_heads, seq = item / (p.n_qblocks * p.n_heads);
   const int row0 = p.cu[seq];
   const int len = p.cu[seq + 1] - row0;
-  const int qb = qblk * 128;
+  const int qb = qblk * BQ;
   if (qb >= len) return;
   int kvlen = len;
   if (p.kv_lens) kvlen = min(max(p.kv_lens[seq], 1), len);
-  const int kv_end = CAUSAL ? min(kvlen, qb + 128) : kvlen;
+  const int kv_end = CAUSAL ? min(kvlen, qb + BQ) : kvlen;
   const int n_tiles = (kv_end + 63) >> 6;
 
-  const int qw = qb + wave * 32;  // first query of this wave
-  const int qpos = qw + ql;       // this lane's query (relative to the sequence)
-  const int qrow = min(qpos, len - 1);
-
-  // ---- Q fragments (B operand of S^T = K Q^T): lane (q, hh) holds Q[q][16ks + 8hh .. +7] ----------
-  bf16x8 qf[KS];
-  {
+  int qw[QB], qpos[QB];           // first query of each of this wave's q-blocks / this lane's query in it
+  bf16x8 qf[QB][KS];              // Q fragments (B operand of S^T = K Q^T): lane (q, hh) holds Q[q][16ks + 8hh .. +7]
+  float gate[QB];
+  const float* bias_row = nullptr;
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    qw[qi] = qb + (wave * QB + qi) * 32;
+    qpos[qi] = qw[qi] + ql;
+    const int qrow = min(qpos[qi], len - 1);
     const unsigned short* qp = p.Q + (int64_t)(row0 + qrow) * p.ldq + head * D + hh * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = *(const bf16x8*)(qp + ks * 16);
+    gate[qi] = 0.f;
+    if (BIAS) gate[qi] = p.rel_gate[(int64_t)(row0 + qrow) * p.n_heads + head] * LOG2E;
   }
-  float gate = 0.f;
-  const float* bias_row = nullptr;
-  if (BIAS) {
-    gate = p.rel_gate[(int64_t)(row0 + qrow) * p.n_heads + head] * LOG2E;
-    bias_row = p.rel_bias + (int64_t)head * (2 * p.rel_span - 1) + (p.rel_span - 1);
-  }
+  if (BIAS) bias_row = p.rel_bias + (int64_t)head * (2 * p.rel_span - 1) + (p.rel_span - 1);
 
   // ---- staging: LDS-DMA with source-side swizzle --------------------------------------------------------
   // DMA instruction j = wave * NCH + i of a tensor covers rows RPI*j .. RPI*j + RPI-1; lane l lands in row RPI*j + l / CPR,
@@ -151,12 +155,17 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     }
   };
 
-  f32x16 o_acc[DB];
+  f32x16 o_acc[QB][DB];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-  for (int d = 0; d < DB; ++d)
+  for (int qi = 0; qi < QB; ++qi) {
+    m_run[qi] = NEG_BIG;
+    l_run[qi] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[qi][d][r] = 0.f;
+  }
 
   // K fragment reads: row kb*32 + ql, logical chunk 2*ks + hh -> physical chunk ^ f_k(row) (f_k(row + 32) = f_k(row))
   int k_off[KS];
@@ -194,86 +203,110 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
     const int k0 = t * 64;
     const char* k_lds = lds + cur * BUF;
     const char* v_lds = k_lds + 64 * ROWB;
-    // wave-uniform: does this wave have any visible key in this tile?
-    const bool active = !CAUSAL || (k0 <= qw + 31);
-    if (active) {
-      // ---- S^T = K Q^T ---------------------------------------------------------------------------
-      f32x16 s_acc[2];
+    // wave-uniform: which of this wave's q-blocks see a key of this tile?
+    bool active[QB];
+    bool any_active = false;
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+      active[qi] = !CAUSAL || (k0 <= qw[qi] + 31);
+      any_active |= active[qi];
+    }
+    if (any_active) {
+      // ---- S^T = K Q^T: every K fragment is read once and feeds all q-blocks --------------------------------
+      f32x16 s_acc[QB][2];
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_acc[qi][kb][r] = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
         const char* kp = k_lds + kb * 32 * ROWB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8 kf = *(const bf16x8*)(kp + k_off[ks]);
-          s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kb], 0, 0, 0);
+#pragma unroll
+          for (int qi = 0; qi < QB; ++qi)
+            if (active[qi]) s_acc[qi][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][ks], s_acc[qi][kb], 0, 0, 0);
         }
       }
-      // ---- scores -> base-2 logits, bias, mask -----------------------------------------------------
-      // need_mask is wave-uniform: interior tiles take the branch-free fast path (raw v_exp_f32, one FMA per score)
-      const bool need_mask = __builtin_amdgcn_readfirstlane((int)((k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw))));
-      float psum = 0.f, alpha;
-      bf16x8 pf[2][2];
-      if (!BIAS && !need_mask) {
-        float tmax = max32_raw(s_acc[0], s_acc[1]);
-        tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;   // scale > 0: max commutes with the scaling
-        const float m_new = max2_raw(m_run, tmax);
-        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+      // ---- scores -> base-2 logits, bias, mask, online softmax; per q-block ---------------------------------------
+      bf16x8 pf[QB][2][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+      for (int qi = 0; qi < QB; ++qi) {
+        if (!active[qi]) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[kb][r], p.scale_log2e, -m_new));
-            psum += e;
-            pf[kb][r >> 3][r & 7] = (__bf16)e;
-          }
-      } else {
-        float tmax = NEG_BIG;
+          for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float v = s_acc[kb][r] * p.scale_log2e;
-            if (BIAS) {
-              int rel = key - qpos;
-              rel = max(-(p.rel_span - 1), min(p.rel_span - 1, rel));
-              v += gate * bias_row[rel];
+              for (int e = 0; e < 8; ++e) pf[qi][kb][h2][e] = (__bf16)0.f;
+          continue;
+        }
+        // need_mask is wave-uniform: interior tiles take the branch-free fast path (raw v_exp_f32, one FMA per score)
+        const bool need_mask = __builtin_amdgcn_readfirstlane((int)((k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw[qi]))));
+        float psum = 0.f, alpha;
+        if (!BIAS && !need_mask) {
+          float tmax = max32_raw(s_acc[qi][0], s_acc[qi][1]);
+          tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;   // scale > 0: max commutes with the scaling
+          const float m_new = max2_raw(m_run[qi], tmax);
+          alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+          m_run[qi] = m_new;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[qi][kb][r], p.scale_log2e, -m_new));
+              psum += e;
+              pf[qi][kb][r >> 3][r & 7] = (__bf16)e;
             }
-            if (need_mask) {
-              const bool ok = (key < kvlen) && (!CAUSAL || key <= qpos);
-              v = ok ? v : NEG_BIG;
+        } else {
+          float tmax;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              float v = s_acc[qi][kb][r] * p.scale_log2e;
+              if (BIAS) {
+                int rel = key - qpos[qi];
+                rel = max(-(p.rel_span - 1), min(p.rel_span - 1, rel));
+                v += gate[qi] * bias_row[rel];
+              }
+              if (need_mask) {
+                const bool ok = (key < kvlen) && (!CAUSAL || key <= qpos[qi]);
+                v = ok ? v : NEG_BIG;
+              }
+              s_acc[qi][kb][r] = v;
             }
-            s_acc[kb][r] = v;
+          }
+          tmax = max32_raw(s_acc[qi][0], s_acc[qi][1]);
+          tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64));
+          const float m_new = max2_raw(m_run[qi], tmax);
+          alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+          m_run[qi] = m_new;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float e = __builtin_amdgcn_exp2f(s_acc[qi][kb][r] - m_new);
+              if (need_mask) e = (s_acc[qi][kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
+              psum += e;
+              pf[qi][kb][r >> 3][r & 7] = (__bf16)e;
+            }
           }
         }
-        tmax = max32_raw(s_acc[0], s_acc[1]);
-        tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = max2_raw(m_run, tmax);
-        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        l_run[qi] = l_run[qi] * alpha + psum;
+        // the running maximum settles after the first tiles: skip the rescale when no query of the wave moved (x * 1.0f is exact)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+          for (int d = 0; d < DB; ++d)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float e = __builtin_amdgcn_exp2f(s_acc[kb][r] - m_new);
-            if (need_mask) e = (s_acc[kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
-            psum += e;
-            pf[kb][r >> 3][r & 7] = (__bf16)e;
-          }
+            for (int r = 0; r < 16; ++r) o_acc[qi][d][r] *= alpha;
         }
       }
-      l_run = l_run * alpha + psum;
-      // the running maximum settles after the first tiles: skip the rescale when no query of the wave moved (x * 1.0f is exact)
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
-      }
-      // ---- O^T += V^T P^T -----------------------------------------------------------------------------
+      // ---- O^T += V^T P^T: every transposed V fragment is read once and feeds all q-blocks ----------------------------
 #pragma unroll
       for (int d = 0; d < DB; ++d) {
 #pragma unroll
@@ -286,7 +319,9 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
             typedef __attribute__((ext_vector_type(8))) short s16x8;
             const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-            o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], o_acc[d], 0, 0, 0);
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+              if (active[qi]) o_acc[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][kb][s], o_acc[qi][d], 0, 0, 0);
           }
         }
       }
@@ -297,18 +332,21 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l -------------------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-  if (qpos < len) {
-    unsigned short* op = p.O + (int64_t)(row0 + qpos) * p.ldo + head * D;
 #pragma unroll
-    for (int d = 0; d < DB; ++d) {
+  for (int qi = 0; qi < QB; ++qi) {
+    const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (qpos[qi] < len) {
+      unsigned short* op = p.O + (int64_t)(row0 + qpos[qi]) * p.ldo + head * D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = d * 32 + 8 * g + 4 * hh;
-        u32x2 pk = {pack_bf16x2(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv),
-                    pack_bf16x2(o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv)};
-        *(u32x2*)(op + d0) = pk;
+      for (int d = 0; d < DB; ++d) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          u32x2 pk = {pack_bf16x2(o_acc[qi][d][4 * g] * inv, o_acc[qi][d][4 * g + 1] * inv),
+                      pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv, o_acc[qi][d][4 * g + 3] * inv)};
+          *(u32x2*)(op + d0) = pk;
+        }
       }
     }
   }
@@ -316,7 +354,8 @@ __global__ __launch_bounds__(256, D == 64 ? 3 : 2) void attn_fwd_kernel(AttnPara
 
 template <int D>
 int launch_attn(const AttnParams& p, const icl_attn_args* a, hipStream_t stream) {
-  dim3 grid(((a->max_seqlen + 127) / 128) * a->n_heads * a->n_seqs, 1, 1);
+  const int bq = (D == 64 && !a->rel_bias) ? 256 : 128;   // queries per workgroup (QB in the kernel)
+  dim3 grid(((a->max_seqlen + bq - 1) / bq) * a->n_heads * a->n_seqs, 1, 1);
   const bool bias = a->rel_bias != nullptr;
   if (a->causal) {
     if (bias)
@@ -360,7 +399,8 @@ extern "C" int icl_attn_fwd_bf16(const icl_attn_args* a, void* stream) {
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
   p.n_heads = a->n_heads;
   p.rel_span = a->rel_span;
-  p.n_qblocks = (a->max_seqlen + 127) / 128;
+  const int bq = (a->head_dim == 64 && !a->rel_bias) ? 256 : 128;
+  p.n_qblocks = (a->max_seqlen + bq - 1) / bq;
   p.scale_log2e = a->scale * LOG2E;
   return a->head_dim == 64 ? launch_attn<64>(p, a, (hipStream_t)stream) : launch_attn<128>(p, a, (hipStream_t)stream);
 }

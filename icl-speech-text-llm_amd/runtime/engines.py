@@ -340,8 +340,13 @@ class LlamaHIP:
         B.rmsnorm(h, L.rms1, xn, c.rms_eps, N=hd)
         if L.lora_a is not None:   # x_aug[:, hd:hd+2r] = x @ (s*A)^T : a skinny GEMM for prefill, a GEMV-style kernel for decode
             # prefill: always the 64x64 tile (the choice must not depend on the batch, or rows would not be batch-invariant);
-            # decode: the skinny kernel (one block, K split over its 8 waves) up to 64 rows
-            B.gemm(xn, L.lora_a, xn[:, hd:hd + L.lora_a.shape[0]], K=hd, tile=4 if (split is not None and M <= 64) else 2)
+            # decode: the skinny kernel (one block, K split over its 8 waves) up to 64 rows, the block-per-row kernel above
+            # that (an N = 16 GEMM on the 64x64 tile is 2 blocks walking all of K: 40 us vs 15)
+            r2 = L.lora_a.shape[0]
+            if split is not None and M > 64:
+                B.lora_down(xn, hd, L.lora_a, r2, 1.0, M=M)      # the LoRA scale is folded into lora_a at pack time
+            else:
+                B.gemm(xn, L.lora_a, xn[:, hd:hd + r2], K=hd, tile=4 if split is not None else 2)
         B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1), workspace=wsk, tile=sk.get("tile", 0))
         B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
         attn_fn(qkv, att)
