@@ -1,7 +1,7 @@
 """Compact a rocprofv3 *_kernel_stats.csv into profiles/<name>.csv (kernel names shortened)."""
 import csv, glob, re, sys
 src_dir, out, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
-f = glob.glob(f"{src_dir}/*/*kernel_stats.csv")[0]
+f = (glob.glob(f"{src_dir}/*/*kernel_stats.csv") + glob.glob(f"{src_dir}/*kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 lines = [f"# {note}", "Name,Calls,TotalDurationNs,AverageNs,Percentage"]
 for r in rows:
