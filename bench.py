@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="utterances per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="run the decode loop eagerly (rocprofv3 --pmc crashes on HIP-graph capture)")
     ap.add_argument("--tiny", action="store_true", help="miniature model (smoke only; not a valid bench number)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c2s", "c4", "c5"],
                     help="BASELINE.md §4: c2 = headline (default); c2s = 5 speech exemplars; c4 = Qwen2-Audio HVB; "
@@ -186,6 +187,8 @@ def main():
     else:
         sd = synth.salmonn_state(cfg, seed=0, device=dev, dtype=torch.bfloat16)   # identical replica on every rank
         rt = SalmonnRuntime(cfg, dict(sd), device=dev)
+    if args.no_graphs:
+        rt.use_graphs = False
     want_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and args.workload == "c2")
     if not want_cpu:
         del sd

@@ -6,7 +6,7 @@ import csv, glob, json, re, sys
 from collections import defaultdict
 
 def collect(d, counter):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
     acc = defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
