@@ -160,12 +160,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    # ICL_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend — lets the N > 1 code path (sharding, gather, max-over-
+    # ranks timing) be exercised on a one-GPU box; never used for reported numbers
+    rehearsal = os.environ.get("ICL_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from icl_speech_text_llm_amd.runtime import binding as B, synth
     from icl_speech_text_llm_amd.runtime.config import SalmonnCfg
