@@ -435,6 +435,50 @@ def g12_qwen_prompts():
     print(f"qwen_prompts.json: {len(out)} prompts")
 
 
+class FakeClock:
+    """Deterministic stand-in for time.time(): advances by a fixed pattern per call."""
+
+    def __init__(self):
+        self.t, self.n = 1000.0, 0
+
+    def __call__(self):
+        self.n += 1
+        self.t += 0.125 + 0.03125 * (self.n % 5)
+        return self.t
+
+
+PERF_UPDATES = [(0.5, 16, None, None), (0.25, 16, 1.5, 480), (0.75, 8, 0.5, 200), (0.125, 1, None, 31), (1.0, 16, 2.0, None),
+                (0.3, 16, None, 512), (0.2, 3, 0.25, 90)]
+
+
+def g13_performance_tracker():
+    """The reference's PerformanceTracker under a fake clock: get_summary() and the periodic log lines."""
+    sys.path.insert(0, REF)
+    import logging
+    import utils.performance_utils as ref
+    out = {}
+    for interval in (3, 100):
+        clock = FakeClock()
+        ref.time.time, lines = clock, []
+
+        class L:
+            def info(self, msg):
+                lines.append(str(msg))
+        try:
+            tr = ref.PerformanceTracker(log_interval=interval, logger=L())
+            for st, bs, loss, tok in PERF_UPDATES:
+                tr.update(st, bs, loss=loss, token_count=tok)
+            summary = tr.get_summary()
+            tr.log_summary()
+        finally:
+            import time as _t
+            ref.time.time = _t.time.__self__.time if hasattr(_t.time, "__self__") else _t.time
+        out[str(interval)] = {"summary": summary, "lines": lines}
+    with open(os.path.join(HERE, "performance_tracker.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("performance_tracker.json:", {k: len(v["lines"]) for k, v in out.items()})
+
+
 DATASET_CASES = [   # (tasks, input_mode, fewshot_mode, num_examples, balance, interleave)
     (["voxceleb"], "speech_only", "text", 5, False, False),
     (["voxceleb"], "speech_only", "speech", 3, False, False),
@@ -553,3 +597,4 @@ if __name__ == "__main__":
     g10_dataset_items()
     g11_sampling()
     g12_qwen_prompts()
+    g13_performance_tracker()

@@ -99,13 +99,13 @@ def test_byte_tokenizer_protocol():
 
 def test_performance_tracker_definition():
     from icl_speech_text_llm_amd.utils.performance_utils import PerformanceTracker
-    t = PerformanceTracker(log_interval=0)
+    t = PerformanceTracker()
     t.start_time -= 2.0
     t.update(0.5, 4)
     t.update(0.25, 4)
     s = t.get_summary()
-    assert s["total_examples"] == 8 and s["total_batches"] == 2 and abs(s["avg_batch_time"] - 0.375) < 1e-9
-    assert 3.5 < s["examples_per_second"] < 4.01       # total_examples / wall time since construction
+    assert s["total_examples"] == 8 and s["step_count"] == 2 and s["avg_step_time"] == "0.3750s"
+    assert 3.5 < float(s["examples_per_second"]) < 4.01       # total_examples / wall time since construction
 
 
 _DP_SCRIPT = r"""
@@ -229,3 +229,37 @@ def test_hf_folder_ingestion_yields_canonical_names(tmp_path):
     with pytest.raises(NotImplementedError, match="grouped-query"):
         ck.llama_cfg_from_hf({"hidden_size": 256, "num_hidden_layers": 1, "num_attention_heads": 4, "num_key_value_heads": 2,
                               "intermediate_size": 512, "vocab_size": 10}, LlamaCfg())
+
+
+def test_performance_tracker_matches_reference(monkeypatch):
+    """a9: PerformanceTracker.update / get_summary / log lines under a fake clock, against the reference's class
+    (tests/golden/make_golden.py::g13_performance_tracker): same keys, same string formats, same definition of examples/s."""
+    import time
+    from icl_speech_text_llm_amd.utils.performance_utils import PerformanceTracker
+
+    class FakeClock:
+        def __init__(self):
+            self.t, self.n = 1000.0, 0
+
+        def __call__(self):
+            self.n += 1
+            self.t += 0.125 + 0.03125 * (self.n % 5)
+            return self.t
+
+    updates = [(0.5, 16, None, None), (0.25, 16, 1.5, 480), (0.75, 8, 0.5, 200), (0.125, 1, None, 31), (1.0, 16, 2.0, None),
+               (0.3, 16, None, 512), (0.2, 3, 0.25, 90)]
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "performance_tracker.json")))
+    for interval, want in gold.items():
+        lines = []
+
+        class L:
+            def info(self, msg):
+                lines.append(str(msg))
+        monkeypatch.setattr(time, "time", FakeClock())
+        tr = PerformanceTracker(log_interval=int(interval), logger=L())
+        for st, bs, loss, tok in updates:
+            tr.update(st, bs, loss=loss, token_count=tok)
+        summary = tr.get_summary()
+        tr.log_summary()
+        monkeypatch.undo()
+        assert summary == want["summary"] and lines == want["lines"], interval
