@@ -7,7 +7,7 @@ from icl_speech_text_llm_amd.runtime import binding as B
 import os
 DEV = "cuda"
 if os.environ.get("ICL_LIB"):
-    B.LIB_PATH = os.environ["ICL_LIB"]      # ablation builds (tools/abl/, not tracked)
+    B.LIB_PATH = os.environ["ICL_LIB"]      # A/B against another build of the library (same box, same call)
 B.load_library()
 which = sys.argv[1] if len(sys.argv) > 1 else "whisper"
 nseq, L, H, D, causal = {"whisper": (64, 1500, 20, 64, False), "llama": (64, 376, 32, 128, True), "beats": (64, 1496, 12, 64, False)}[which]
