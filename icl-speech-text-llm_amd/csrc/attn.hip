@@ -63,8 +63,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 template <int D, bool CAUSAL, bool BIAS>
 __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
   // 32-query blocks per wave: at D = 64 two of them share every K and V fragment read, every staged byte and every
-  // barrier (the loop is issue-bound, not MFMA-bound); the gated-bias variant keeps one (its 32 table gathers per tile and
-  // lane want the third wave per SIMD more than the sharing: 3.2 ms vs 2.4 ms per BEATs layer at 128 clips)
+  // barrier (the loop is issue-bound, not MFMA-bound); the gated-bias variant keeps one (measured: its longer per-score
+  // sequence wants the third wave per SIMD more than the sharing, 407 vs 385 TF/s on the BEATs shape)
   constexpr int QB = (D == 64 && !BIAS) ? 2 : 1;
   constexpr int BQ = 128 * QB;      // queries per workgroup
   constexpr int ROWB = D * 2;       // bytes per K / V row in LDS (unpadded: LDS-DMA writes lane-linear)
@@ -77,6 +77,10 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
   constexpr int NBUF = D == 64 ? 3 : 2;   // ring depth: tiles are staged NBUF-1 iterations ahead (D=128: 2 x 32 KiB keeps 2 blocks/CU)
   constexpr int AHEAD = NBUF - 1;
   __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF];   // ONE barrier per KV tile
+  // gated relative-position bias: per tile and q-block the 95 table entries a wave can touch (rel = key - query over
+  // 64 keys x 32 queries) are staged once into a wave-private LDS window; a score then costs one ds_read_b32 at
+  // base + immediate instead of clamp + 64-bit address + global gather
+  __shared__ float bias_win[BIAS ? 4 * QB * 128 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hh = lane >> 5;
@@ -263,17 +267,25 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
             }
         } else {
           float tmax;
+          const float* win = nullptr;
+          if (BIAS) {
+            float* w = bias_win + (wave * QB + qi) * 128;
+            const int base_rel = k0 - qw[qi] - 31;          // window index i <-> rel = base_rel + i, i in [0, 95)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int rel = max(-(p.rel_span - 1), min(p.rel_span - 1, base_rel + lane + 64 * i));
+              w[lane + 64 * i] = bias_row[rel];
+            }
+            __builtin_amdgcn_wave_barrier();                 // same wave, in-order LDS queue: the reads below see the writes
+            win = w + (4 * hh - ql + 31);
+          }
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
               float v = s_acc[qi][kb][r] * p.scale_log2e;
-              if (BIAS) {
-                int rel = key - qpos[qi];
-                rel = max(-(p.rel_span - 1), min(p.rel_span - 1, rel));
-                v += gate[qi] * bias_row[rel];
-              }
+              if (BIAS) v = fmaf(gate[qi], win[kb * 32 + (r & 3) + 8 * (r >> 2)], v);
               if (need_mask) {
                 const bool ok = (key < kvlen) && (!CAUSAL || key <= qpos[qi]);
                 v = ok ? v : NEG_BIG;
