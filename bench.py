@@ -302,6 +302,33 @@ def main():
         for k, (fl, tt, n) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:40]:
             log(f"gemm tile={k[0]} sk={k[1]} M={k[2]} N={k[3]} K={k[4]} batch={k[5]}: {n} launches, {tt / n * 1e6:9.1f} us avg, "
                 f"{fl / tt / 1e12:7.1f} TF/s, {100 * tt / elapsed:5.1f}% of step time")
+    # ---- per-phase timing: ONE extra, untimed step with HIP events at the phase boundaries -----------------
+    phases = None
+    if rank == 0 and args.workload == "c2" and not args.tiny:
+        marks = {k: torch.cuda.Event(enable_timing=True) for k in ("enc_start", "prefill_start", "prefill_end", "decode_end")}
+        rt.phase_marks = marks
+        marks["enc_start"].record()
+        step(total_steps - 1)
+        torch.cuda.synchronize()
+        rt.phase_marks = None
+        t_enc = marks["enc_start"].elapsed_time(marks["prefill_start"]) * 1e-3      # front-ends, encoders, Q-Former, prompt gather
+        t_pre = marks["prefill_start"].elapsed_time(marks["prefill_end"]) * 1e-3
+        t_dec = marks["prefill_end"].elapsed_time(marks["decode_end"]) * 1e-3
+        S = wl_text[0] + wl_naudio * audio_tokens
+        kv_bytes = sum(0.524288e6 * (S + t) for t in range(1, NEW_TOKENS)) * Bm       # K+V bf16, 32 layers x 4096, re-read per step
+        phases = {
+            "encoder": {"ms": round(t_enc * 1e3, 1), "tflop": round(2.647 * Bm, 1),
+                        "mfma_frac": round(2.647e12 * Bm / t_enc / 2.5e15, 3)},
+            "prefill": {"ms": round(t_pre * 1e3, 1), "tflop": round(4.907 * Bm, 1),
+                        "mfma_frac": round(4.907e12 * Bm / t_pre / 2.5e15, 3)},
+            "decode": {"ms": round(t_dec * 1e3, 1), "steps": NEW_TOKENS - 1,
+                       "hbm_gb": round((13.48e9 * (NEW_TOKENS - 1) + kv_bytes) / 1e9, 1),
+                       "hbm_frac": round((13.48e9 * (NEW_TOKENS - 1) + kv_bytes) / t_dec / 8.0e12, 3)},
+            "note": "one untimed step after the timed region, HIP events at the phase boundaries; FLOPs / bytes per utterance from "
+                    "SURVEY.md §8d (encoder 2.647 TFLOP, prefill 4.907 TFLOP at 376 positions, decode = 13.48 GB of weights per step "
+                    "+ the K/V of every sequence); peaks 2.5 PFLOP/s bf16 dense and 8 TB/s",
+        }
+        log(f"phases: encoder {t_enc * 1e3:.1f} ms, prefill {t_pre * 1e3:.1f} ms, decode {t_dec * 1e3:.1f} ms")
     if rank == 0:
         n_utt = Bm * args.steps * world
         out = {
@@ -315,7 +342,7 @@ def main():
                        "prompt_positions": [t + wl_naudio * audio_tokens for t in wl_text] if len(wl_text) > 1 else wl_text[0] + wl_naudio * audio_tokens,
                        "audio_seconds": 30, "new_tokens": NEW_TOKENS, "parallelism": f"dp{world}",
                        "weights": "seeded N(0,0.02^2) bf16, LoRA r=8 un-merged"},
-            "roofline": roof,
+            "roofline": roof, "phases": phases,
             "build_s": round(t_build, 1), "first_utterance_tokens": first_tokens,
         }
         if want_cpu:

@@ -130,6 +130,9 @@ class CausalLMRuntimeMixin:
         max_len = -(-need // cache_len_multiple) * cache_len_multiple
         assert max_len <= c.max_pos, f"prompt + new tokens ({need}) exceeds max_pos {c.max_pos}"
         cache = self._cache(Bn, max_len)
+        marks = getattr(self, "phase_marks", None)     # optional {name: torch.cuda.Event}: bench.py times prefill / decode with it
+        if marks is not None:
+            marks["prefill_start"].record()
         self.llama.prefill(ws, h, lens, cache)
         cu_last = []
         acc = 0
@@ -140,6 +143,8 @@ class CausalLMRuntimeMixin:
         B.gather_rows(h, _i32(cu_last, dev), last)
         logits = self.llama.logits(ws, last, name="gen_logits")
         first = logits.clone() if want_first_logits else None
+        if marks is not None:
+            marks["prefill_end"].record()
         finished = ws.get("gen_finished", (Bn,), I32)
         finished.zero_()
         toks = ws.get("gen_tokens", (Bn, max_new_tokens), I32)
@@ -196,6 +201,8 @@ class CausalLMRuntimeMixin:
             else:
                 decode_loop()
                 self._graph_warm.add(gkey)
+        if marks is not None:
+            marks["decode_end"].record()
         out = toks.cpu().to(torch.int64)                                                 # the only D2H of the call
         width = max_new_tokens
         if eos >= 0:
