@@ -48,23 +48,35 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
   v[1] = (__bf16)hi;
   return __builtin_bit_cast(unsigned int, v);
 }
-// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): one v_rcp + one v_exp + 6 FMA
-// instead of libm erff's ~40 instructions — the GELU epilogue of a K=1280 GEMM is otherwise VALU-bound.
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-  float poly = 1.061405429f;
-  poly = poly * t - 1.453152027f;
-  poly = poly * t + 1.421413741f;
-  poly = poly * t - 0.284496736f;
-  poly = poly * t + 0.254829592f;
-  const float r = 1.0f - poly * t * __expf(-ax * ax);
-  return copysignf(r, x);
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), arranged for the GEMM epilogues (128 values
+// per thread, VALU-bound next to a K = 1280 main loop):  gelu(x) = relu(x) - |x| q,  q = (P(t)/2) t exp(-x^2/2),
+// t = 1 / (1 + (p/sqrt 2) |x|)  — for x >= 0 that is x - x q = x Phi(x), for x < 0 it is -|x| q = x (1 - Phi(|x|)).
+// One v_rcp_f32, one v_exp_f32 (base 2, the 1/2 log2 e folded into the argument), explicit FMAs only (the same
+// contraction at every call site: all tile shapes must round alike), written on pairs so that hipcc emits v_pk_fma_f32 /
+// v_pk_mul_f32 (two values per issue slot).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 den = __builtin_elementwise_fma(ax, f32x2{0.23164189f, 0.23164189f}, one);   // 0.3275911 / sqrt(2)
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 poly = {0.5306027145f, 0.5306027145f};                                            // A-S coefficients / 2
+  poly = __builtin_elementwise_fma(poly, t, f32x2{-0.7265760135f, -0.7265760135f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.7107068705f, 0.7107068705f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{-0.142248368f, -0.142248368f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.127414796f, 0.127414796f});
+  const f32x2 arg = (x * x) * f32x2{-0.72134752044f, -0.72134752044f};                    // -x^2/2 * log2(e)
+  const f32x2 e = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+  const f32x2 q = (poly * t) * e;
+  const f32x2 relu = __builtin_elementwise_max(x, f32x2{0.0f, 0.0f});
+  return __builtin_elementwise_fma(-ax, q, relu);
 }
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
+  const f32x2 a = gelu_erf2(f32x2{v[0], v[1]}), b = gelu_erf2(f32x2{v[2], v[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2{x, x})[0]; }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // no IEEE division sequence
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll

@@ -14,6 +14,7 @@
 // Tiles: 128x128 (2x2 waves, 4x4 MFMA tiles per wave) for prefill/encoder shapes,
 //        64x64   (2x2 waves, 2x2 MFMA tiles per wave) for skinny / decode shapes (+ split-K).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -50,8 +51,9 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, int z, int m, in
       if (full || n + r < p.N) v[r] += p.bias[n + r];
   }
   if (has_gelu) {
+    const f32x4 g = gelu_erf4(f32x4{v[0], v[1], v[2], v[3]});
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    for (int r = 0; r < 4; ++r) v[r] = g[r];
   }
   const int64_t coff = cz + (int64_t)m * p.ldc + n;
   if (full && vec_ok) {
@@ -244,7 +246,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const bool vecp = p.split_k == 1 && vec_path_ok(p);
   const bool interior = vecp && (m0 + BM <= p.M) && (n0 + BN <= p.N);
   const bool fold_bias = vecp && (p.epi & ICL_EPI_BIAS);
-  const bool fold_res = vecp && (p.epi & ICL_EPI_RESIDUAL) && p.res_dtype == ICL_F32 && !(p.epi & (ICL_EPI_GELU | ICL_EPI_SWIGLU));
+  // the residual is added LAST, (bias + sum) + r, in every kernel and every tile (interior, edge, any tile shape): the order
+  // is part of the batch-invariance contract; the 256x256 kernel reads it as whole rows in its LDS-staged epilogue
+  constexpr bool fold_res = false;
 
   // order matters: pure loads first (no use -> no wait), then the LDS-DMA of K-tile 0, then the first use (one wait
   // that covers everything); a use placed between loads would make hipcc drain vmcnt(0) per load.
@@ -333,8 +337,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       for (int j = 0; j < NI; ++j) {
         f32x4 v = acc[i][j];
         if (p.epi & ICL_EPI_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            v = gelu_erf4(v);
         }
         if (late_res) v = v + rv[i][j];
         store_out4(p, (int64_t)z * p.sC + (int64_t)(mb + i * 16) * p.ldc + nb + j * 16, v);
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
 // =================================================================================================================
 constexpr int T256_REGION = 128 * 128;          // bytes
 constexpr int T256_BUF = 4 * T256_REGION;       // A0 A1 B0 B1
-constexpr int T256_SMEM = 2 * T256_BUF;         // 131072
+constexpr int T256_SMEM = 128 * (256 * 4 + 16);   // 133120: the two K-tile buffers (131072) / the C staging of the epilogue
 
 __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -447,9 +450,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
       gsrc[0][h][r] = A + (int64_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + chunk * 8;
       gsrc[1][h][r] = p.W + (int64_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + chunk * 8;
     }
-  auto stage = [&](int buf, int which, int h, int kt) {   // which: 0 = A, 1 = B
+  auto stage = [&](int bo, int which, int h, int kt) {   // bo: byte offset of the K-tile buffer (0 | T256_BUF); which: 0 = A, 1 = B
     const int64_t koff = (int64_t)min(kt, nk - 1) * 64;
-    char* base = smem + buf * T256_BUF + (which * 2 + h) * T256_REGION + wave * 1024;
+    char* base = smem + bo + (which * 2 + h) * T256_REGION + wave * 1024;
     __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[which][h][0] + koff), (lptr_t)(base), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[which][h][1] + koff), (lptr_t)(base + 8 * 1024), 16, 0, 0);
   };
@@ -472,18 +475,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
   const bool vecp = vec_path_ok(p);
   const bool interior = vecp && (m0 + 256 <= p.M) && (n0 + 256 <= p.N);
   const bool fold_bias = vecp && (p.epi & ICL_EPI_BIAS);
-  const bool fold_res = vecp && (p.epi & ICL_EPI_RESIDUAL) && p.res_dtype == ICL_F32 && !(p.epi & (ICL_EPI_GELU | ICL_EPI_SWIGLU));
+  // the residual is added LAST, (bias + sum) + r, in every kernel and every tile (interior, edge, any tile shape): the order
+  // is part of the batch-invariance contract; the 256x256 kernel reads it as whole rows in its LDS-staged epilogue
+  constexpr bool fold_res = false;
 
-  auto read_a = [&](int buf, int h) {
-    const char* r = smem + buf * T256_BUF + h * T256_REGION + a_base;
+  auto read_a = [&](int bo, int h) {
+    const char* r = smem + bo + h * T256_REGION + a_base;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       af[i][0] = *(const bf16x8*)(r + i * 2048 + sw0);
       af[i][1] = *(const bf16x8*)(r + i * 2048 + sw1);
     }
   };
-  auto read_b = [&](int buf, int h, bf16x8 (&bf)[2][2]) {
-    const char* r = smem + buf * T256_BUF + (2 + h) * T256_REGION + b_base;
+  auto read_b = [&](int bo, int h, bf16x8 (&bf)[2][2]) {
+    const char* r = smem + bo + (2 + h) * T256_REGION + b_base;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       bf[j][0] = *(const bf16x8*)(r + j * 2048 + sw0);
@@ -507,34 +512,50 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto phase_sync = [&]() {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  // the phase's counted wait (N = LDS-DMA instructions that may stay in flight: 8 = four granules in steady state) + barrier
+  auto phase_sync = [&](auto n_tag) {
+    constexpr int N = decltype(n_tag)::value;
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto tile = [&](int buf, int t) {
+  // MODE 0: steady state (every phase stages one granule 5-6 phases ahead, vmcnt(8)); bo / bo ^ T256_BUF = this / the other
+  // K-tile buffer.  MODE 1 / 2: K-tiles nk-2 / nk-1: stage-ahead targets past the end of K are NOT issued (no dummy re-loads,
+  // no drain before the block retires); each wait lets exactly the instructions issued in the last four phases stay in
+  // flight, which shrinks 8 -> 6 -> 4 -> 2 -> 0 as the staging runs dry, so the guarantee "the granule staged four phases
+  // ago has landed" is the one of the steady state.
+  auto tile = [&](int bo, int t, auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+    const int bx = bo ^ T256_BUF;
     // P0
-    read_a(buf, 0);
-    read_b(buf, 0, b0f);
-    stage(buf ^ 1, 1, 1, t + 1);
-    phase_sync();
+    read_a(bo, 0);
+    read_b(bo, 0, b0f);
+    if constexpr (MODE != 2) stage(bx, 1, 1, t + 1);
+    phase_sync(std::integral_constant<int, MODE == 2 ? 2 : 8>{});
     mma(acc[0][0], b0f);
     // P1
-    read_b(buf, 1, b1f);
-    stage(buf ^ 1, 0, 1, t + 1);
-    phase_sync();
+    read_b(bo, 1, b1f);
+    if constexpr (MODE != 2) stage(bx, 0, 1, t + 1);
+    phase_sync(std::integral_constant<int, MODE == 2 ? 0 : 8>{});
     mma(acc[0][1], b1f);
     // P2
-    read_a(buf, 1);
-    stage(buf, 0, 0, t + 2);
-    phase_sync();
+    read_a(bo, 1);
+    if constexpr (MODE == 0) stage(bo, 0, 0, t + 2);
+    phase_sync(std::integral_constant<int, MODE == 0 ? 8 : (MODE == 1 ? 6 : 0)>{});
     mma(acc[1][1], b1f);
     // P3
-    stage(buf, 1, 0, t + 2);
-    phase_sync();
+    if constexpr (MODE == 0) stage(bo, 1, 0, t + 2);
+    phase_sync(std::integral_constant<int, MODE == 0 ? 8 : (MODE == 1 ? 4 : 0)>{});
     mma(acc[1][0], b0f);
   };
+  using M0_ = std::integral_constant<int, 0>;
+  using M1_ = std::integral_constant<int, 1>;
+  using M2_ = std::integral_constant<int, 2>;
 
   // accumulator init = (f32 residual) + bias: pure loads issued BEFORE the prologue's LDS-DMA, first use after it;
   // tile-independent decision (vec_path_ok), edge tiles only add bounds guards
@@ -568,8 +589,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
   stage(0, 1, 0, 0);
   stage(0, 1, 1, 0);
   stage(0, 0, 1, 0);
-  stage(1, 0, 0, 1);
-  stage(1, 1, 0, 1);
+  stage(T256_BUF, 0, 0, 1);
+  stage(T256_BUF, 1, 0, 1);
   __builtin_amdgcn_sched_barrier(0);
   if (fold_bias) {   // first use of the pre-loaded operands: ONE wait covers loads and prologue
 #pragma unroll
@@ -581,18 +602,101 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[qa][qb][i][j] = acc[qa][qb][i][j] + bias_f[qb][j];
   }
-  phase_sync();
+  phase_sync(std::integral_constant<int, 8>{});
   if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0 (hazard analysis in DESIGN.md §4)
+  // K-tiles 0 .. nk-3 in steady state (compile-time buffers), then the two tail K-tiles on a run-time buffer offset (the host
+  // sends K < 128 to the other tiles: nk >= 2 here)
+  const int n_steady = nk - 2;
   int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    tile(0, t);
-    tile(1, t + 1);
+  for (; t + 1 < n_steady; t += 2) {
+    tile(0, t, M0_{});
+    tile(T256_BUF, t + 1, M0_{});
   }
-  if (t < nk) tile(0, t);
+  if (t < n_steady) {
+    tile(0, t, M0_{});
+    ++t;
+  }
+  const int bo = (t & 1) ? T256_BUF : 0;
+  tile(bo, t, M1_{});
+  tile(bo ^ T256_BUF, t + 1, M2_{});
   if (wr == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count of the two groups
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail re-loads before the block retires
 
-  if (interior) {
+  // ---- interior tiles: the C tile leaves through LDS ---------------------------------------------------------------
+  // An MFMA fragment gives a lane 4 consecutive columns of ONE row, so direct stores are 8-B (bf16) pieces in 32-B row
+  // segments: 32 partial-line stores per thread, measured at 6.4 us per tile (21 % of a K = 1280 tile, 6 % at K = 4096; the
+  // same kernel without its stores runs 1.39 PF/s at K = 1280).  The K-tile buffers are dead after the main loop, so each
+  // 128-row half of the tile is written to LDS in its output type (row pitch + 16 B: conflict-free for both the fragment
+  // writes and the row reads) and read back as whole rows, 16 B per lane, full cache lines per wave-instruction.
+  const int es_out = p.out_dtype == ICL_BF16 ? 2 : 4;
+  const bool rows16 = (((uintptr_t)p.C | (uintptr_t)(p.ldc * es_out) | (uintptr_t)(p.sC * es_out)) & 15) == 0;   // whole rows in 16-B pieces
+  const bool has_res = p.epi & ICL_EPI_RESIDUAL;
+  const bool res_rows = has_res && p.res_dtype == ICL_F32 && p.out_dtype == ICL_F32 && !(p.epi & ICL_EPI_SWIGLU) &&
+                        (((uintptr_t)p.R | (uintptr_t)(p.ldr * 4) | (uintptr_t)(p.sR * 4)) & 15) == 0;
+  if (interior && rows16 && (!has_res || res_rows)) {
+    const bool swiglu = p.epi & ICL_EPI_SWIGLU;
+    const bool obf = p.out_dtype == ICL_BF16;
+    const int out_cols = swiglu ? 128 : 256;
+    const int es = obf ? 2 : 4;
+    const int pitch = out_cols * es + 16;                        // bytes per staged row
+    const int chunks_per_row = out_cols * es / 16;               // 16-B pieces per row: 16 | 32 | 64
+    const int64_t c_col0 = swiglu ? (n0 >> 1) : n0;
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa) {
+      __syncthreads();                                           // K-tile reads (qa = 0) / the previous half's row reads are done
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wr * 64 + i * 16 + fr;
+          if (swiglu) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(acc[qa][qb][i][0][r]) * acc[qa][qb][i][1][r];
+            const int col = qb * 64 + wc * 16 + fq * 4;
+            char* dst = smem + row * pitch + col * es;
+            if (obf) *(u32x2*)dst = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            else *(f32x4*)dst = v;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              f32x4 v = acc[qa][qb][i][j];
+              if (p.epi & ICL_EPI_GELU) {
+            v = gelu_erf4(v);
+              }
+              const int col = qb * 128 + wc * 32 + j * 16 + fq * 4;
+              char* dst = smem + row * pitch + col * es;
+              if (obf) *(u32x2*)dst = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              else *(f32x4*)dst = v;
+            }
+          }
+        }
+      __syncthreads();
+      char* cbase = (char*)p.C + ((int64_t)z * p.sC + (int64_t)(m0 + qa * 128) * p.ldc + c_col0) * es;
+      const int n_chunks = 128 * chunks_per_row;                 // 2048 | 4096 | 8192: a multiple of the 512 threads
+      if (has_res) {   // f32 residual stream: whole-row 16-B loads, all of a thread's 16 issued before the first use
+        const char* rbase = (const char*)p.R + ((int64_t)z * p.sR + (int64_t)(m0 + qa * 128) * p.ldr + n0) * 4;
+        f32x4 rr[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int c = tid + it * 512, row = c >> 6, cc = c & 63;
+          rr[it] = *(const f32x4*)(rbase + (int64_t)row * p.ldr * 4 + cc * 16);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int c = tid + it * 512, row = c >> 6, cc = c & 63;
+          const f32x4 v = *(const f32x4*)(smem + row * pitch + cc * 16) + rr[it];
+          *(f32x4*)(cbase + (int64_t)row * p.ldc * 4 + cc * 16) = v;
+        }
+      } else {
+        for (int c = tid; c < n_chunks; c += 512) {
+          const int row = c / chunks_per_row, cc = c - row * chunks_per_row;
+          const u32x4 v = *(const u32x4*)(smem + row * pitch + cc * 16);
+          *(u32x4*)(cbase + (int64_t)row * p.ldc * es + cc * 16) = v;
+        }
+      }
+    }
+    return;
+  } else if (interior) {
     const bool late_res = (p.epi & ICL_EPI_RESIDUAL) && !fold_res;
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
@@ -627,8 +731,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
           for (int j = 0; j < 2; ++j) {
             f32x4 v = acc[qa][qb][i][j];
             if (p.epi & ICL_EPI_GELU) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            v = gelu_erf4(v);
             }
             if (late_res) v = v + rv[qb][i][j];
             store_out4(p, (int64_t)z * p.sC + (int64_t)(mb + i * 16) * p.ldc + n0 + qb * 128 + wc * 32 + j * 16 + fq * 4, v);
@@ -874,6 +977,7 @@ extern "C" int icl_gemm_bf16(const icl_gemm_args* a, void* stream_) {
 
   int tile = a->tile;
   if (tile == 0) tile = icl_gemm_select_tile(a->M, a->N, a->K, a->batch, a->split_k);
+  if (tile == 3 && a->K < 128) tile = 1;   // the 256x256 pipeline peels two K-tiles; same arithmetic on the 128x128 tile
   int rc;
   if (tile == 1)
     rc = launch_tile<2, 2, 4, 4>(p, a->batch, stream);

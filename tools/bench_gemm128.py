@@ -5,7 +5,10 @@ import torch
 sys.path.insert(0, ".")
 from icl_speech_text_llm_amd.runtime import binding as B
 
+import os
 DEV = "cuda"
+if os.environ.get("ICL_LIB"):
+    B.LIB_PATH = os.environ["ICL_LIB"]
 
 
 def timeit(fn, iters=10, warmup=2):
