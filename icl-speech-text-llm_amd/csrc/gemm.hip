@@ -425,7 +425,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
 // =================================================================================================================
 constexpr int T256_REGION = 128 * 128;          // bytes
 constexpr int T256_BUF = 4 * T256_REGION;       // A0 A1 B0 B1
-constexpr int T256_SMEM = 128 * (256 * 4 + 16);   // 133120: the two K-tile buffers (131072) / the C staging of the epilogue
+constexpr int T256_SMEM = 256 * (256 * 2 + 16);   // 135168: the two K-tile buffers (131072) / the C staging of the epilogue
+                                                  // (whole bf16 tile, or one 128-row half in f32: 133120)
 
 __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -640,14 +641,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
     const int pitch = out_cols * es + 16;                        // bytes per staged row
     const int chunks_per_row = out_cols * es / 16;               // 16-B pieces per row: 16 | 32 | 64
     const int64_t c_col0 = swiglu ? (n0 >> 1) : n0;
+    const bool one_round = obf;                                  // a bf16 tile fits whole: two barriers instead of four
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
-      __syncthreads();                                           // K-tile reads (qa = 0) / the previous half's row reads are done
+      if (qa == 0 || !one_round) __syncthreads();                // K-tile reads (qa = 0) / the previous half's row reads are done
+      const int row_off = one_round ? qa * 128 : 0;
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int row = wr * 64 + i * 16 + fr;
+          const int row = row_off + wr * 64 + i * 16 + fr;
           if (swiglu) {
             f32x4 v;
 #pragma unroll
@@ -670,9 +673,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
             }
           }
         }
+      if (one_round && qa == 0) continue;
       __syncthreads();
-      char* cbase = (char*)p.C + ((int64_t)z * p.sC + (int64_t)(m0 + qa * 128) * p.ldc + c_col0) * es;
-      const int n_chunks = 128 * chunks_per_row;                 // 2048 | 4096 | 8192: a multiple of the 512 threads
+      char* cbase = (char*)p.C + ((int64_t)z * p.sC + (int64_t)(m0 + (one_round ? 0 : qa * 128)) * p.ldc + c_col0) * es;
+      const int n_chunks = (one_round ? 256 : 128) * chunks_per_row;   // a multiple of the 512 threads
       if (has_res) {   // f32 residual stream: whole-row 16-B loads, all of a thread's 16 issued before the first use
         const char* rbase = (const char*)p.R + ((int64_t)z * p.sR + (int64_t)(m0 + qa * 128) * p.ldr + n0) * 4;
         f32x4 rr[16];
