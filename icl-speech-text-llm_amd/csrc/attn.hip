@@ -344,10 +344,43 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l -------------------------------------------------------------
+  // A lane owns one query ROW, so direct stores are 8-B pieces at a row stride: every store instruction touches 64 cache
+  // lines.  The K/V ring is dead after the loop's last barrier: each wave transposes its rows through a private LDS region
+  // and stores whole head-rows (D * 2 bytes = one or two full lines), 16 B per lane.
+  float inv[QB];
 #pragma unroll
   for (int qi = 0; qi < QB; ++qi) {
     const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    inv[qi] = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  }
+  const bool rows16 = (((uintptr_t)p.O | (uintptr_t)(p.ldo * 2)) & 15) == 0;
+  if (rows16) {
+    constexpr int PITCH = D * 2 + 16;
+    constexpr int LPR = D * 2 / 16, RPI = 64 / LPR;     // lanes per row, rows per store instruction
+    char* stg = lds + wave * (QB * 32 * PITCH);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          *(u32x2*)(stg + (qi * 32 + ql) * PITCH + d0 * 2) =
+              u32x2{pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                    pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+        }
+    __builtin_amdgcn_wave_barrier();                    // same wave, in-order LDS queue
+#pragma unroll
+    for (int it = 0; it < QB * 32 / RPI; ++it) {
+      const int row = it * RPI + lane / LPR, cc = lane % LPR;
+      const int q = qw[row >> 5] + (row & 31);
+      const u32x4 v = *(const u32x4*)(stg + row * PITCH + cc * 16);
+      if (q < len) *(u32x4*)(p.O + (int64_t)(row0 + q) * p.ldo + head * D + cc * 8) = v;
+    }
+    return;
+  }
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
     if (qpos[qi] < len) {
       unsigned short* op = p.O + (int64_t)(row0 + qpos[qi]) * p.ldo + head * D;
 #pragma unroll
@@ -355,8 +388,8 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d0 = d * 32 + 8 * g + 4 * hh;
-          u32x2 pk = {pack_bf16x2(o_acc[qi][d][4 * g] * inv, o_acc[qi][d][4 * g + 1] * inv),
-                      pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv, o_acc[qi][d][4 * g + 3] * inv)};
+          u32x2 pk = {pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                      pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
           *(u32x2*)(op + d0) = pk;
         }
       }
