@@ -21,41 +21,62 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(unsigned short* qkv, int64
   const int rope_items = 2 * H * per_head; // q and k
   unsigned short* row = qkv + m * ld;
   const int64_t cache_row = kc ? ((int64_t)seq_ids[m] * H) * max_len + p : 0;
-  for (int it = threadIdx.x; it < rope_items; it += blockDim.x) {
-    const int which = it / (H * per_head);          // 0 = q, 1 = k
-    const int rem = it - which * H * per_head;
-    const int h = rem / per_head, i0 = (rem - h * per_head) * 8;
-    unsigned short* base = row + (which ? k_off : 0) + h * D;
-    const u32x4 lo = *(const u32x4*)(base + i0);
-    const u32x4 hi = *(const u32x4*)(base + i0 + half);
-    const f32x4 c0 = *(const f32x4*)(cosT + (int64_t)p * half + i0);
-    const f32x4 c1 = *(const f32x4*)(cosT + (int64_t)p * half + i0 + 4);
-    const f32x4 s0 = *(const f32x4*)(sinT + (int64_t)p * half + i0);
-    const f32x4 s1 = *(const f32x4*)(sinT + (int64_t)p * half + i0 + 4);
-    u32x4 olo, ohi;
+  // Two rope items and two V items per thread per pass, ALL loads issued before the first use: with one small block per
+  // row the kernel is latency-bound on bytes in flight per thread (2.8 TB/s with the loads interleaved with their uses).
+  constexpr int U = 2;
+  const int v_items = vc ? H * (D >> 3) : 0;
+  for (int base = threadIdx.x; base < rope_items || base < v_items; base += U * blockDim.x) {
+    u32x4 lo[U], hi[U], vv[U];
+    f32x4 c0[U], c1[U], s0[U], s1[U];
+    unsigned short* rb[U];
+    int i0s[U], hs[U], whichs[U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float a0 = __uint_as_float(lo[j] << 16), a1 = __uint_as_float(lo[j] & 0xffff0000u);
-      const float b0 = __uint_as_float(hi[j] << 16), b1 = __uint_as_float(hi[j] & 0xffff0000u);
-      const float cA = j < 2 ? c0[2 * j] : c1[2 * j - 4], cB = j < 2 ? c0[2 * j + 1] : c1[2 * j - 3];
-      const float sA = j < 2 ? s0[2 * j] : s1[2 * j - 4], sB = j < 2 ? s0[2 * j + 1] : s1[2 * j - 3];
-      olo[j] = pack_bf16x2(a0 * cA - b0 * sA, a1 * cB - b1 * sB);
-      ohi[j] = pack_bf16x2(b0 * cA + a0 * sA, b1 * cB + a1 * sB);
+    for (int u = 0; u < U; ++u) {
+      const int it = base + u * blockDim.x;
+      if (it < rope_items) {
+        const int which = it / (H * per_head);          // 0 = q, 1 = k
+        const int rem = it - which * H * per_head;
+        const int h = rem / per_head, i0 = (rem - h * per_head) * 8;
+        unsigned short* bp = row + (which ? k_off : 0) + h * D;
+        rb[u] = bp; i0s[u] = i0; hs[u] = h; whichs[u] = which;
+        lo[u] = *(const u32x4*)(bp + i0);
+        hi[u] = *(const u32x4*)(bp + i0 + half);
+        c0[u] = *(const f32x4*)(cosT + (int64_t)p * half + i0);
+        c1[u] = *(const f32x4*)(cosT + (int64_t)p * half + i0 + 4);
+        s0[u] = *(const f32x4*)(sinT + (int64_t)p * half + i0);
+        s1[u] = *(const f32x4*)(sinT + (int64_t)p * half + i0 + 4);
+      }
+      if (it < v_items) {
+        const int h = it / (D >> 3), i0 = (it - h * (D >> 3)) * 8;
+        vv[u] = *(const u32x4*)(row + v_off + h * D + i0);
+      }
     }
-    *(u32x4*)(base + i0) = olo;
-    *(u32x4*)(base + i0 + half) = ohi;
-    if (which == 1 && kc) {
-      unsigned short* dst = kc + (cache_row + (int64_t)h * max_len) * D;
-      *(u32x4*)(dst + i0) = olo;
-      *(u32x4*)(dst + i0 + half) = ohi;
-    }
-  }
-  if (vc) {
-    const int v_items = H * (D >> 3);
-    for (int it = threadIdx.x; it < v_items; it += blockDim.x) {
-      const int h = it / (D >> 3), i0 = (it - h * (D >> 3)) * 8;
-      const u32x4 v = *(const u32x4*)(row + v_off + h * D + i0);
-      *(u32x4*)(vc + (cache_row + (int64_t)h * max_len) * D + i0) = v;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = base + u * blockDim.x;
+      if (it < rope_items) {
+        u32x4 olo, ohi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a0 = __uint_as_float(lo[u][j] << 16), a1 = __uint_as_float(lo[u][j] & 0xffff0000u);
+          const float b0 = __uint_as_float(hi[u][j] << 16), b1 = __uint_as_float(hi[u][j] & 0xffff0000u);
+          const float cA = j < 2 ? c0[u][2 * j] : c1[u][2 * j - 4], cB = j < 2 ? c0[u][2 * j + 1] : c1[u][2 * j - 3];
+          const float sA = j < 2 ? s0[u][2 * j] : s1[u][2 * j - 4], sB = j < 2 ? s0[u][2 * j + 1] : s1[u][2 * j - 3];
+          olo[j] = pack_bf16x2(a0 * cA - b0 * sA, a1 * cB - b1 * sB);
+          ohi[j] = pack_bf16x2(b0 * cA + a0 * sA, b1 * cB + a1 * sB);
+        }
+        *(u32x4*)(rb[u] + i0s[u]) = olo;
+        *(u32x4*)(rb[u] + i0s[u] + half) = ohi;
+        if (whichs[u] == 1 && kc) {
+          unsigned short* dst = kc + (cache_row + (int64_t)hs[u] * max_len) * D;
+          *(u32x4*)(dst + i0s[u]) = olo;
+          *(u32x4*)(dst + i0s[u] + half) = ohi;
+        }
+      }
+      if (it < v_items) {
+        const int h = it / (D >> 3), i0 = (it - h * (D >> 3)) * 8;
+        *(u32x4*)(vc + (cache_row + (int64_t)h * max_len) * D + i0) = vv[u];
+      }
     }
   }
 }
