@@ -23,28 +23,92 @@ __device__ __forceinline__ int float_to_ordered(float f) {
 }
 __device__ __forceinline__ float ordered_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 
-// power[f][bin] = |sum_n frames[f][n] * exp(-2 pi i bin n / NFFT)|^2 for one bin per thread
-template <int NFFT, int NB>
-__device__ __forceinline__ void dft_power(const double* frames, const double* tw, double* power) {
-  const int bin = threadIdx.x;
-  if (bin < NB) {
-    double re[FR], im[FR];
-#pragma unroll
-    for (int f = 0; f < FR; ++f) re[f] = im[f] = 0.0;
-    int idx = 0;
-    for (int n = 0; n < WLEN; ++n) {
-      const double c = tw[2 * idx], s = tw[2 * idx + 1];
-#pragma unroll
-      for (int f = 0; f < FR; ++f) {
-        const double x = frames[f * WLEN + n];
-        re[f] += x * c;
-        im[f] -= x * s;
-      }
-      idx += bin;
-      if (idx >= NFFT) idx -= NFFT;
+// power[f][bin] = |sum_n x[f][n] * exp(-2 pi i bin n / NFFT)|^2, one bin per thread, x real with x[n] = 0 for n >= WLEN.
+// Real-input symmetry: cos(2 pi k (N-n)/N) = cos(2 pi k n/N) and sin(...(N-n)) = -sin(...n), so with
+//   s[n] = x[n] + x[N-n],  d[n] = x[n] - x[N-n]   (n = 1 .. N/2-1, folded IN PLACE into the frame rows beforehand)
+//   Re X[k] = x[0] + (-1)^k x[N/2] + sum_n s[n] cos(2 pi k n/N),   Im X[k] = -sum_n d[n] sin(2 pi k n/N)
+// the loop runs over N/2-1 sample pairs with one twiddle read and 2 FMAs per frame each: half the FMAs and half the LDS
+// twiddle traffic of the plain sum.  FSTR = row pitch of the frame array (>= NFFT so that n and N-n both have a slot).
+template <int NFFT, int FSTR>
+__device__ __forceinline__ void fold_frames(double* frames) {
+  constexpr int HALF = NFFT / 2;
+  for (int i = threadIdx.x; i < FR * (HALF - 1); i += blockDim.x) {
+    const int f = i / (HALF - 1), n = 1 + i - f * (HALF - 1);
+    if (NFFT - n < WLEN) {          // the partner sample exists (always for NFFT = WLEN; n >= NFFT - WLEN + 1 when zero-padded)
+      double* row = frames + f * FSTR;
+      const double a = row[n], b = row[NFFT - n];
+      row[n] = a + b;
+      row[NFFT - n] = a - b;
     }
+  }
+}
+// Bin symmetry on top of it: theta_n(N/2 - k) = pi n - theta_n(k), so cos -> (-1)^n cos and sin -> -(-1)^n sin.  With the
+// sums split by the parity of n,  E = sum_even s[n] cos, O = sum_odd s[n] cos, Ei = sum_even d[n] sin, Oi = sum_odd d[n] sin:
+//   X[k]       = (x0 + (-1)^k xh + E + O) - i (Ei + Oi)
+//   X[N/2 - k] = (x0 + (-1)^(N/2-k) xh + E - O) + i (Ei - Oi)
+// one thread produces BOTH bins from one pass over the sample pairs: a quarter of the plain sum's FMAs and LDS reads.
+template <int NFFT, int NB, int FSTR>
+__device__ __forceinline__ void dft_power(const double* frames, const double* tw, double* power) {
+  constexpr int HALF = NFFT / 2, QUART = NFFT / 4;
+  static_assert(NFFT % 4 == 0, "bin pairing needs NFFT % 4 == 0");
+  const int bin = threadIdx.x;                 // 0 .. NFFT/4; partner bin = NFFT/2 - bin
+  if (bin <= QUART) {
+    double e[FR], o[FR], ei[FR], oi[FR];
 #pragma unroll
-    for (int f = 0; f < FR; ++f) power[f * NB + bin] = re[f] * re[f] + im[f] * im[f];
+    for (int f = 0; f < FR; ++f) e[f] = o[f] = ei[f] = oi[f] = 0.0;
+    int idx = bin;
+    for (int n = 1; n < HALF; n += 2) {        // n odd, then n + 1 even
+      {
+        const double c = tw[2 * idx], s = tw[2 * idx + 1];
+        const int nd = (NFFT - n < WLEN) ? NFFT - n : n;
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+          o[f] += frames[f * FSTR + n] * c;
+          oi[f] += frames[f * FSTR + nd] * s;
+        }
+        idx += bin;
+        if (idx >= NFFT) idx -= NFFT;
+      }
+      if (n + 1 < HALF) {
+        const double c = tw[2 * idx], s = tw[2 * idx + 1];
+        const int m = n + 1, nd = (NFFT - m < WLEN) ? NFFT - m : m;
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+          e[f] += frames[f * FSTR + m] * c;
+          ei[f] += frames[f * FSTR + nd] * s;
+        }
+        idx += bin;
+        if (idx >= NFFT) idx -= NFFT;
+      }
+    }
+    const int pb = HALF - bin;                 // partner bin
+    const double sg = (bin & 1) ? -1.0 : 1.0, sp = (pb & 1) ? -1.0 : 1.0;
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      const double x0 = frames[f * FSTR], xh = HALF < WLEN ? frames[f * FSTR + HALF] : 0.0;
+      const double re = x0 + sg * xh + e[f] + o[f], im = ei[f] + oi[f];
+      power[f * NB + bin] = re * re + im * im;
+      if (pb < NB && pb != bin) {
+        const double re2 = x0 + sp * xh + e[f] - o[f], im2 = ei[f] - oi[f];
+        power[f * NB + pb] = re2 * re2 + im2 * im2;
+      }
+    }
+  }
+}
+
+// [lo, hi) of the non-zero taps of every (triangular, contiguous) mel filter, found once per block: the projection then
+// walks 5-30 bins per filter instead of all of them
+__device__ __forceinline__ void mel_ranges(const double* mel, int n_mel, int row_ld, int n_bins, int* lo, int* hi) {
+  for (int m = threadIdx.x; m < n_mel; m += blockDim.x) {
+    const double* mf = mel + (int64_t)m * row_ld;
+    int a = n_bins, b = 0;
+    for (int k = 0; k < n_bins; ++k)
+      if (mf[k] != 0.0) {
+        a = min(a, k);
+        b = k + 1;
+      }
+    lo[m] = min(a, b);
+    hi[m] = b;
   }
 }
 
@@ -65,10 +129,12 @@ __global__ __launch_bounds__(256) void whisper_logmel_kernel(const float* wav, i
   __shared__ double frames[FR * WLEN];
   __shared__ double tw[2 * WH_NFFT];
   __shared__ double power[FR * WH_BINS];
+  __shared__ int mlo[128], mhi[128];
   const int a = blockIdx.y, f0 = blockIdx.x * FR;
   const float* w = wav + (int64_t)a * wav_ld;
   const int L = min(wav_lens[a], WH_SAMPLES);
   fill_twiddles<WH_NFFT>(tw);
+  mel_ranges(mel, n_mel, WH_BINS, WH_BINS, mlo, mhi);
   __syncthreads();
   // centre frames over the zero-padded 480000-sample signal with reflect padding of n_fft/2
   for (int i = threadIdx.x; i < FR * WLEN; i += blockDim.x) {
@@ -80,7 +146,9 @@ __global__ __launch_bounds__(256) void whisper_logmel_kernel(const float* wav, i
     frames[i] = x * (0.5 - 0.5 * tw[2 * n]);  // periodic Hann: cos(2 pi n / 400) is the twiddle
   }
   __syncthreads();
-  dft_power<WH_NFFT, WH_BINS>(frames, tw, power);
+  fold_frames<WH_NFFT, WLEN>(frames);
+  __syncthreads();
+  dft_power<WH_NFFT, WH_BINS, WLEN>(frames, tw, power);
   __syncthreads();
   float local_max = -INFINITY;
   for (int o = threadIdx.x; o < n_mel * FR; o += blockDim.x) {
@@ -89,7 +157,7 @@ __global__ __launch_bounds__(256) void whisper_logmel_kernel(const float* wav, i
     const double* mf = mel + (int64_t)m * WH_BINS;
     const double* pw = power + f * WH_BINS;
     double acc = 0.0;
-    for (int b = 0; b < WH_BINS; ++b) acc += mf[b] * pw[b];
+    for (int b = mlo[m]; b < mhi[m]; ++b) acc += mf[b] * pw[b];
     const float lv = (float)log10(fmax(acc, 1e-10));
     raw[((int64_t)a * n_mel + m) * WH_FRAMES + f0 + f] = lv;
     local_max = fmaxf(local_max, lv);
@@ -144,12 +212,14 @@ __global__ __launch_bounds__(256) void kaldi_fbank_kernel(const float* wav, int6
   __shared__ double tw[2 * FB_NFFT];
   __shared__ double power[FR * FB_BINS];
   __shared__ double fmean[FR];
+  __shared__ int mlo[FB_MEL], mhi[FB_MEL];
   const int a = blockIdx.y, f0 = blockIdx.x * FR;
   const float* w = wav + (int64_t)a * wav_ld;
   const int L = wav_lens[a];
   const int n_frames = L >= WLEN ? 1 + (L - WLEN) / HOP : 0;
   if (f0 >= min(n_frames, max_frames)) return;
   fill_twiddles<FB_NFFT>(tw);
+  mel_ranges(mel, FB_MEL, FB_BINS + 1, FB_BINS, mlo, mhi);
   // raw frames (x * 2^15), snip_edges framing
   for (int i = threadIdx.x; i < FR * WLEN; i += blockDim.x) {
     const int f = i / WLEN, n = i - f * WLEN;
@@ -190,7 +260,9 @@ __global__ __launch_bounds__(256) void kaldi_fbank_kernel(const float* wav, int6
     }
   }
   __syncthreads();
-  dft_power<FB_NFFT, FB_BINS>(frames, tw, power);
+  fold_frames<FB_NFFT, WLEN>(frames);
+  __syncthreads();
+  dft_power<FB_NFFT, FB_BINS, WLEN>(frames, tw, power);
   __syncthreads();
   for (int o = threadIdx.x; o < FB_MEL * FR; o += blockDim.x) {
     const int f = o / FB_MEL, m = o - f * FB_MEL;
@@ -198,7 +270,7 @@ __global__ __launch_bounds__(256) void kaldi_fbank_kernel(const float* wav, int6
     const double* mf = mel + (int64_t)m * (FB_BINS + 1);
     const double* pw = power + f * FB_BINS;
     double acc = 0.0;
-    for (int b = 0; b < FB_BINS; ++b) acc += mf[b] * pw[b];
+    for (int b = mlo[m]; b < mhi[m]; ++b) acc += mf[b] * pw[b];
     const double lv = log(fmax(acc, 1.1920928955078125e-07));
     out[((int64_t)a * max_frames + f0 + f) * FB_MEL + m] = (float)((lv - (double)mean) / (2.0 * (double)stdv));
   }
