@@ -4,9 +4,10 @@
 // Both are tiny (≈1 GFLOP per 30 s clip) and are computed in f64 (direct DFT from an LDS twiddle
 // table: n_fft = 400 is not a power of two and MI355X has full-rate f64 vector FMA), so the result
 // is closer to the exact value than the reference's f32 FFT; outputs are f32.
-// Layout: one block = FR consecutive frames of one audio; frames are staged (windowed) in LDS and
-// every thread owns one frequency bin for all FR frames (the frame sample is an LDS broadcast, the
-// twiddle a per-lane LDS read).  Loads of the waveform are coalesced; nothing is re-read from HBM.
+// Layout: one block = FR consecutive frames of one audio; frames are staged (windowed) in LDS, folded into
+// s[n] = x[n] + x[N-n], d[n] = x[n] - x[N-n], and every thread owns a PAIR of frequency bins (k, N/2 - k) for all
+// FR frames (the frame sample is an LDS broadcast, the twiddle a per-lane LDS read shared by both bins): a quarter of
+// the plain DFT's FMAs and LDS reads.  Loads of the waveform are coalesced; nothing is re-read from HBM.
 #include "common.h"
 
 namespace {
