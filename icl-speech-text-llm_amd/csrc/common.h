@@ -48,6 +48,21 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
   v[1] = (__bf16)hi;
   return __builtin_bit_cast(unsigned int, v);
 }
+// RoPE on eight (i, i + D/2) pairs of one head (HF rotate_half pairing): lo/hi hold 8 bf16 each, c0|c1 and s0|s1 the eight
+// f32 cos/sin values of those columns.  Products and sums are rounded separately (no FMA contraction) — the arithmetic of
+// the f32 oracle — and the function is shared by the rope kernel and the fused QKV-GEMM epilogue so that both round alike.
+__device__ __forceinline__ void rope_rot8(u32x4 lo, u32x4 hi, f32x4 c0, f32x4 c1, f32x4 s0, f32x4 s1, u32x4& olo,
+                                          u32x4& ohi) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a0 = __uint_as_float(lo[j] << 16), a1 = __uint_as_float(lo[j] & 0xffff0000u);
+    const float b0 = __uint_as_float(hi[j] << 16), b1 = __uint_as_float(hi[j] & 0xffff0000u);
+    const float cA = j < 2 ? c0[2 * j] : c1[2 * j - 4], cB = j < 2 ? c0[2 * j + 1] : c1[2 * j - 3];
+    const float sA = j < 2 ? s0[2 * j] : s1[2 * j - 4], sB = j < 2 ? s0[2 * j + 1] : s1[2 * j - 3];
+    olo[j] = pack_bf16x2(__fsub_rn(__fmul_rn(a0, cA), __fmul_rn(b0, sA)), __fsub_rn(__fmul_rn(a1, cB), __fmul_rn(b1, sB)));
+    ohi[j] = pack_bf16x2(__fadd_rn(__fmul_rn(b0, cA), __fmul_rn(a0, sA)), __fadd_rn(__fmul_rn(b1, cB), __fmul_rn(a1, sB)));
+  }
+}
 // exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), arranged for the GEMM epilogues (128 values
 // per thread, VALU-bound next to a K = 1280 main loop):  gelu(x) = relu(x) - |x| q,  q = (P(t)/2) t exp(-x^2/2),
 // t = 1 / (1 + (p/sqrt 2) |x|)  — for x >= 0 that is x - x q = x Phi(x), for x < 0 it is -|x| q = x (1 - Phi(|x|)).

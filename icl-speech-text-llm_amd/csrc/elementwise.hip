@@ -56,15 +56,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(unsigned short* qkv, int64
       const int it = base + u * blockDim.x;
       if (it < rope_items) {
         u32x4 olo, ohi;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a0 = __uint_as_float(lo[u][j] << 16), a1 = __uint_as_float(lo[u][j] & 0xffff0000u);
-          const float b0 = __uint_as_float(hi[u][j] << 16), b1 = __uint_as_float(hi[u][j] & 0xffff0000u);
-          const float cA = j < 2 ? c0[u][2 * j] : c1[u][2 * j - 4], cB = j < 2 ? c0[u][2 * j + 1] : c1[u][2 * j - 3];
-          const float sA = j < 2 ? s0[u][2 * j] : s1[u][2 * j - 4], sB = j < 2 ? s0[u][2 * j + 1] : s1[u][2 * j - 3];
-          olo[j] = pack_bf16x2(a0 * cA - b0 * sA, a1 * cB - b1 * sB);
-          ohi[j] = pack_bf16x2(b0 * cA + a0 * sA, b1 * cB + a1 * sB);
-        }
+        rope_rot8(lo[u], hi[u], c0[u], c1[u], s0[u], s1[u], olo, ohi);
         *(u32x4*)(rb[u] + i0s[u]) = olo;
         *(u32x4*)(rb[u] + i0s[u] + half) = ohi;
         if (whichs[u] == 1 && kc) {

@@ -428,7 +428,90 @@ constexpr int T256_BUF = 4 * T256_REGION;       // A0 A1 B0 B1
 constexpr int T256_SMEM = 256 * (256 * 2 + 16);   // 135168: the two K-tile buffers (131072) / the C staging of the epilogue
                                                   // (whole bf16 tile, or one 128-row half in f32: 133120)
 
-__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
+// Fused RoPE + KV-cache append for the QKV projection (icl_gemm_rope_kv_bf16): the row phase of the staged epilogue.
+// head_dim = 128, so a 256-column tile holds two whole heads of q, of k or of v; the staged tile is bf16, i.e. the
+// rotation sees exactly the values the unfused path would have read back from HBM (same rounding points, rope_rot8).
+struct RopeFuse {
+  const float* cosT;
+  const float* sinT;
+  const int* pos;
+  const int* seq_ids;
+  unsigned short* kc;
+  unsigned short* vc;
+  int k_off, v_off, H, max_len;
+};
+
+__device__ __forceinline__ void rope_rows(const GemmParams& p, const RopeFuse& rf, const char* smem, int pitch, int m0,
+                                          int n0, int tid) {
+  const int sect = n0 >= rf.v_off ? 2 : (n0 >= rf.k_off ? 1 : 0);
+  const int head0 = (n0 - (sect == 2 ? rf.v_off : sect == 1 ? rf.k_off : 0)) >> 7;
+  unsigned short* C = (unsigned short*)p.C;
+  constexpr int U = 4;
+  if (sect == 2) {   // v: whole rows to the QKV buffer and to the cache
+    for (int base = tid; base < 256 * 32; base += U * 512) {
+      int64_t crow[U];
+      if (rf.vc) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int m = min(m0 + ((base + u * 512) >> 5), p.M - 1);
+          crow[u] = (int64_t)rf.seq_ids[m] * rf.H * rf.max_len + rf.pos[m];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = base + u * 512, row = c >> 5, cc = c & 31, m = m0 + row;
+        if (m >= p.M) continue;
+        const u32x4 v = *(const u32x4*)(smem + row * pitch + cc * 16);
+        *(u32x4*)(C + (int64_t)m * p.ldc + n0 + cc * 8) = v;
+        if (rf.vc) *(u32x4*)(rf.vc + (crow[u] + (int64_t)(head0 + (cc >> 4)) * rf.max_len) * 128 + (cc & 15) * 8) = v;
+      }
+    }
+    return;
+  }
+  const bool to_cache = sect == 1 && rf.kc;
+  for (int base = tid; base < 256 * 16; base += U * 512) {   // items: (row, head-in-tile, 8-column piece of the low half)
+    int ps[U], sq[U];
+    u32x4 lo[U], hi[U];
+    f32x4 c0[U], c1[U], s0[U], s1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = min(m0 + ((base + u * 512) >> 4), p.M - 1);
+      ps[u] = rf.pos[m];
+      sq[u] = to_cache ? rf.seq_ids[m] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = base + u * 512, row = it >> 4, hh = (it >> 3) & 1, j = it & 7;
+      const char* src = smem + row * pitch + hh * 256 + j * 16;
+      lo[u] = *(const u32x4*)src;
+      hi[u] = *(const u32x4*)(src + 128);
+      const float* cp = rf.cosT + (int64_t)ps[u] * 64 + j * 8;
+      const float* sp = rf.sinT + (int64_t)ps[u] * 64 + j * 8;
+      c0[u] = *(const f32x4*)cp;
+      c1[u] = *(const f32x4*)(cp + 4);
+      s0[u] = *(const f32x4*)sp;
+      s1[u] = *(const f32x4*)(sp + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = base + u * 512, row = it >> 4, hh = (it >> 3) & 1, j = it & 7, m = m0 + row;
+      if (m >= p.M) continue;
+      u32x4 olo, ohi;
+      rope_rot8(lo[u], hi[u], c0[u], c1[u], s0[u], s1[u], olo, ohi);
+      unsigned short* dst = C + (int64_t)m * p.ldc + n0 + hh * 128 + j * 8;
+      *(u32x4*)dst = olo;
+      *(u32x4*)(dst + 64) = ohi;
+      if (to_cache) {
+        unsigned short* cd = rf.kc + (((int64_t)sq[u] * rf.H + head0 + hh) * rf.max_len + ps[u]) * 128 + j * 8;
+        *(u32x4*)cd = olo;
+        *(u32x4*)(cd + 64) = ohi;
+      }
+    }
+  }
+}
+
+template <bool ROPE>
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p, RopeFuse rf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -633,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
   const bool has_res = p.epi & ICL_EPI_RESIDUAL;
   const bool res_rows = has_res && p.res_dtype == ICL_F32 && p.out_dtype == ICL_F32 && !(p.epi & ICL_EPI_SWIGLU) &&
                         (((uintptr_t)p.R | (uintptr_t)(p.ldr * 4) | (uintptr_t)(p.sR * 4)) & 15) == 0;
-  if (interior && rows16 && (!has_res || res_rows)) {
+  if (ROPE || (interior && rows16 && (!has_res || res_rows))) {   // ROPE: the host has checked the layout; row-masked M edge
     const bool swiglu = p.epi & ICL_EPI_SWIGLU;
     const bool obf = p.out_dtype == ICL_BF16;
     const int out_cols = swiglu ? 128 : 256;
@@ -641,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
     const int pitch = out_cols * es + 16;                        // bytes per staged row
     const int chunks_per_row = out_cols * es / 16;               // 16-B pieces per row: 16 | 32 | 64
     const int64_t c_col0 = swiglu ? (n0 >> 1) : n0;
-    const bool one_round = obf;                                  // a bf16 tile fits whole: two barriers instead of four
+    const bool one_round = ROPE || obf;                          // a bf16 tile fits whole: two barriers instead of four
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
       if (qa == 0 || !one_round) __syncthreads();                // K-tile reads (qa = 0) / the previous half's row reads are done
@@ -675,6 +758,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
         }
       if (one_round && qa == 0) continue;
       __syncthreads();
+      if constexpr (ROPE) {   // (not a return: an early exit inside the qa loop keeps hipcc from unrolling it -> acc in scratch)
+        rope_rows(p, rf, smem, pitch, m0, n0, tid);
+        continue;
+      }
       char* cbase = (char*)p.C + ((int64_t)z * p.sC + (int64_t)(m0 + (one_round ? 0 : qa * 128)) * p.ldc + c_col0) * es;
       const int n_chunks = (one_round ? 256 : 128) * chunks_per_row;   // a multiple of the 512 threads
       if (has_res) {   // f32 residual stream: whole-row 16-B loads, all of a thread's 16 issued before the first use
@@ -766,19 +853,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p) {
     }
 }
 
-int launch_tile256(GemmParams& p, int batch, hipStream_t stream) {
+int launch_tile256(GemmParams& p, int batch, hipStream_t stream, const RopeFuse* rope = nullptr) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T256_SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_SMEM);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm256_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_SMEM);
     if (e != hipSuccess) {
       icl_set_error("icl_gemm_bf16: hipFuncSetAttribute(%d) failed: %s", T256_SMEM, hipGetErrorString(e));
       return ICL_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(p.tiles_m * p.tiles_n, 1, batch), dim3(512), T256_SMEM, stream, p);
+  const dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
+  if (rope)
+    hipLaunchKernelGGL(gemm256_bf16_kernel<true>, grid, dim3(512), T256_SMEM, stream, p, *rope);
+  else
+    hipLaunchKernelGGL(gemm256_bf16_kernel<false>, grid, dim3(512), T256_SMEM, stream, p, RopeFuse{});
   ICL_CHECK_LAUNCH("icl_gemm_bf16(256)");
   return ICL_OK;
 }
@@ -921,7 +1014,7 @@ extern "C" int icl_gemm_select_tile(int32_t M, int32_t N, int32_t K, int32_t bat
   return 1;
 }
 
-extern "C" int icl_gemm_bf16(const icl_gemm_args* a, void* stream_) {
+static int gemm_impl(const icl_gemm_args* a, void* stream_, const RopeFuse* rope) {
   hipStream_t stream = (hipStream_t)stream_;
   ICL_CHECK_ARG(a != nullptr, "icl_gemm_bf16: args is NULL");
   ICL_CHECK_ARG(a->A && a->W && a->C, "icl_gemm_bf16: A/W/C must be non-NULL");
@@ -982,6 +1075,12 @@ extern "C" int icl_gemm_bf16(const icl_gemm_args* a, void* stream_) {
   int tile = a->tile;
   if (tile == 0) tile = icl_gemm_select_tile(a->M, a->N, a->K, a->batch, a->split_k);
   if (tile == 3 && a->K < 128) tile = 1;   // the 256x256 pipeline peels two K-tiles; same arithmetic on the 128x128 tile
+  if (rope) {
+    ICL_CHECK_ARG(tile == 3, "icl_gemm_rope_kv_bf16: only the 256x256 tile fuses RoPE (this problem resolves to tile %d; "
+                             "use icl_gemm_bf16 + icl_rope_kv_bf16)", tile);
+    ICL_CHECK_ARG(a->split_k == 1, "icl_gemm_rope_kv_bf16: split_k must be 1");
+    return launch_tile256(p, 1, stream, rope);
+  }
   int rc;
   if (tile == 1)
     rc = launch_tile<2, 2, 4, 4>(p, a->batch, stream);
@@ -1011,4 +1110,31 @@ extern "C" int icl_gemm_bf16(const icl_gemm_args* a, void* stream_) {
     ICL_CHECK_LAUNCH("icl_gemm_bf16(split-K reduce)");
   }
   return ICL_OK;
+}
+
+extern "C" int icl_gemm_bf16(const icl_gemm_args* a, void* stream) { return gemm_impl(a, stream, nullptr); }
+
+extern "C" int icl_gemm_rope_kv_bf16(const icl_gemm_args* a, int64_t k_off, int64_t v_off, const float* cosT,
+                                     const float* sinT, const int32_t* pos, const int32_t* seq_ids, void* kcache,
+                                     void* vcache, int32_t n_heads, int32_t head_dim, int32_t max_len, void* stream) {
+  ICL_CHECK_ARG(a != nullptr && cosT && sinT && pos, "icl_gemm_rope_kv_bf16: NULL pointer");
+  ICL_CHECK_ARG(head_dim == 128, "icl_gemm_rope_kv_bf16: head_dim=%d (the fused epilogue is built for 128)", head_dim);
+  ICL_CHECK_ARG(n_heads > 0 && k_off == (int64_t)n_heads * 128 && v_off == 2 * k_off && a->N == 3 * k_off && k_off % 256 == 0,
+                "icl_gemm_rope_kv_bf16: need q|k|v blocks of n_heads*128 columns each, a multiple of 256 (N=%d k_off=%lld v_off=%lld)",
+                a->N, (long long)k_off, (long long)v_off);
+  ICL_CHECK_ARG(a->batch == 1 && a->out_dtype == ICL_BF16 && (a->epilogue & ~ICL_EPI_BIAS) == 0,
+                "icl_gemm_rope_kv_bf16: batch 1, bf16 output, bias-only epilogue");
+  ICL_CHECK_ARG(a->C && ((uintptr_t)a->C & 15) == 0 && a->ldc % 8 == 0, "icl_gemm_rope_kv_bf16: C must be 16-byte aligned, ldc %% 8 == 0");
+  ICL_CHECK_ARG(!a->bias || ((uintptr_t)a->bias & 15) == 0, "icl_gemm_rope_kv_bf16: bias must be 16-byte aligned");
+  ICL_CHECK_ARG(((uintptr_t)cosT & 15) == 0 && ((uintptr_t)sinT & 15) == 0, "icl_gemm_rope_kv_bf16: cos/sin misaligned");
+  ICL_CHECK_ARG((kcache == nullptr) == (vcache == nullptr), "icl_gemm_rope_kv_bf16: kcache and vcache must both be set or both NULL");
+  if (kcache) {
+    ICL_CHECK_ARG(seq_ids && max_len > 0, "icl_gemm_rope_kv_bf16: cache append needs seq_ids and max_len");
+    ICL_CHECK_ARG(((uintptr_t)kcache & 15) == 0 && ((uintptr_t)vcache & 15) == 0, "icl_gemm_rope_kv_bf16: cache misaligned");
+  }
+  RopeFuse rf;
+  rf.cosT = cosT; rf.sinT = sinT; rf.pos = pos; rf.seq_ids = seq_ids;
+  rf.kc = (unsigned short*)kcache; rf.vc = (unsigned short*)vcache;
+  rf.k_off = (int)k_off; rf.v_off = (int)v_off; rf.H = n_heads; rf.max_len = max_len;
+  return gemm_impl(a, stream, &rf);
 }

@@ -67,6 +67,8 @@ _SIGNATURES = {
                             c_int32, c_int32, c_void_p]),
     "icl_rope_kv_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "icl_gemm_rope_kv_bf16": (c_int, [POINTER(GemmArgs), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "icl_embed_gather_interleave": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                             c_int32, c_int32, c_void_p]),
     "icl_argmax_eos": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
@@ -154,8 +156,11 @@ def _require_gpu(*tensors):
 # ------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, residual=None, gelu=False,
          swiglu=False, split_k: int = 1, workspace=None, tile: int = 0, M=None, K=None, lda=None,
-         batch: int = 1, stride_a: int = 0, stride_c: int = 0, stride_r: int = 0) -> torch.Tensor:
-    """out = epilogue(a @ w.T).  a: bf16 [M,K] (row stride lda), w: bf16 [N,K], out: bf16|f32 [M,N']."""
+         batch: int = 1, stride_a: int = 0, stride_c: int = 0, stride_r: int = 0, rope=None) -> torch.Tensor:
+    """out = epilogue(a @ w.T).  a: bf16 [M,K] (row stride lda), w: bf16 [N,K], out: bf16|f32 [M,N'].
+
+    ``rope`` = (k_off, v_off, cos, sin, pos, seq_ids, kcache, vcache, n_heads, head_dim, max_len) runs the QKV projection
+    with RoPE + KV-cache append fused into its epilogue (icl_gemm_rope_kv_bf16; see ``rope_fusable``)."""
     _require_gpu(a, w, out, bias, residual, workspace)
     lib = load_library()
     g = GemmArgs()
@@ -190,15 +195,33 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, resi
     g.tile = tile
     if split_k > 1 and workspace is not None:
         assert workspace.dtype == torch.float32 and workspace.numel() >= split_k * g.M * N
+    if rope is not None:
+        k_off, v_off, cos, sin, pos, seq_ids, kcache, vcache, n_heads, head_dim, max_len = rope
+        _require_gpu(cos, sin, pos, seq_ids, kcache, vcache)
+
+        def launch():
+            _check(lib.icl_gemm_rope_kv_bf16(ctypes.byref(g), k_off, v_off, cos.data_ptr(), sin.data_ptr(), pos.data_ptr(),
+                                             _ptr(seq_ids), _ptr(kcache), _ptr(vcache), n_heads, head_dim, max_len,
+                                             _stream()), "icl_gemm_rope_kv_bf16")
+    else:
+        def launch():
+            _check(lib.icl_gemm_bf16(ctypes.byref(g), _stream()), "icl_gemm_bf16")
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _check(lib.icl_gemm_bf16(ctypes.byref(g), _stream()), "icl_gemm_bf16")
+        launch()
         e1.record()
         GEMM_PROFILE.append((tile, split_k, 2.0 * g.M * N * g.K * batch, e0, e1, (g.M, N, g.K, batch)))
         return out
-    _check(lib.icl_gemm_bf16(ctypes.byref(g), _stream()), "icl_gemm_bf16")
+    launch()
     return out
+
+
+def rope_fusable(M: int, n_heads: int, head_dim: int, K: int) -> bool:
+    """True when the QKV projection [M, 3*n_heads*head_dim] x K runs on the 256x256 tile with the fused RoPE epilogue."""
+    hd = n_heads * head_dim
+    return (head_dim == 128 and hd % 256 == 0 and K >= 128 and
+            load_library().icl_gemm_select_tile(M, 3 * hd, K, 1, 1) == 3)
 
 
 def attn_fwd(q, k, v, out, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: int, scale: float, *,

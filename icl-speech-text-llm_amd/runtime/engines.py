@@ -347,8 +347,13 @@ class LlamaHIP:
                 B.lora_down(xn, hd, L.lora_a, r2, 1.0, M=M)      # the LoRA scale is folded into lora_a at pack time
             else:
                 B.gemm(xn, L.lora_a, xn[:, hd:hd + r2], K=hd, tile=4 if split is not None else 2)
-        B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1), workspace=wsk, tile=sk.get("tile", 0))
-        B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
+        if split is None and B.rope_fusable(M, H, D, L.wqkv.shape[1]):
+            # prefill on the 256x256 tile: RoPE + cache append run in the GEMM's staged epilogue (same bits as the two calls)
+            B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, tile=3,
+                   rope=(hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len))
+        else:
+            B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1), workspace=wsk, tile=sk.get("tile", 0))
+            B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
         attn_fn(qkv, att)
         B.gemm(att, L.wo, h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=sk.get("tile", 0))
         B.rmsnorm(h, L.rms2, xn, c.rms_eps, N=hd)

@@ -169,6 +169,22 @@ int icl_rope_kv_bf16(void* qkv, int64_t ld, int64_t k_off, int64_t v_off, const 
                      void* vcache, int32_t M, int32_t n_heads, int32_t head_dim, int32_t max_len,
                      void* stream);
 
+/* ---- K10/K11: QKV projection with RoPE + KV-cache append fused into its epilogue -----------
+ * icl_gemm_bf16(args) followed by icl_rope_kv_bf16 on its output, as ONE kernel: the 256x256 tile
+ * stages its bf16 C tile through LDS, and with head_dim = 128 a tile is two whole heads of q, k or
+ * v, so the row phase rotates (q, k), stores the rows and appends k/v to the cache — the QKV rows
+ * are not read back from HBM.  Bit-identical to the two-call sequence (same rounding points).
+ * args: batch 1, bf16 output, epilogue 0 or ICL_EPI_BIAS, N = 3*n_heads*128 with q|k|v column
+ * blocks at 0 | k_off | v_off, n_heads*128 a multiple of 256; the problem must resolve to the
+ * 256x256 tile (icl_gemm_select_tile(...) == 3 and K >= 128) — otherwise ICL_EINVAL, and the
+ * caller issues the two calls.  Remaining arguments as icl_rope_kv_bf16.
+ * Replaces q_proj/k_proj/v_proj + apply_rotary_pos_emb + DynamicCache.update of transformers'
+ * LlamaAttention, reached from models/custom_salmon.py:630-636 (prefill).
+ */
+int icl_gemm_rope_kv_bf16(const icl_gemm_args* args, int64_t k_off, int64_t v_off, const float* cos,
+                          const float* sin, const int32_t* pos, const int32_t* seq_ids, void* kcache,
+                          void* vcache, int32_t n_heads, int32_t head_dim, int32_t max_len, void* stream);
+
 /* ---- K9: token-embedding gather + speech interleave --------------------------------------
  * out[r][:] = src_idx[r] >= 0 ? table[src_idx[r]][:] : speech[-src_idx[r]-1][:]
  * table bf16 [vocab][H]; speech f32 [n_speech_rows][H]; out f32 [rows][H].

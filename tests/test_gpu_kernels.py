@@ -382,6 +382,50 @@ def test_rope_kv(B):
         assert torch.equal(vc[sid[m], :, pos[m]], orig[m, 2 * H * D:].view(H, D))
 
 
+@pytest.mark.parametrize("M,with_bias", [(600, True), (512, False), (77, True)])
+def test_gemm_rope_kv_fused_is_bit_identical(B, M, with_bias):
+    """The QKV projection with RoPE + cache append in its epilogue == icl_gemm_bf16 followed by icl_rope_kv_bf16, bit for bit
+    (interior tiles, a partial last row of tiles, a single partial tile; with and without the Qwen2 qkv bias)."""
+    H, D, K, max_len = 4, 128, 576, 256
+    hd = H * D
+    x, w = _rand_bf16(M, K, seed=51), _rand_bf16(3 * hd, K, seed=52, scale=0.05)
+    bias = torch.randn(3 * hd, device=DEV) if with_bias else None
+    lens = [M // 3, M // 3, M - 2 * (M // 3)]
+    pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens]).to(DEV)
+    sid = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(lens)]).to(DEV)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2, device=DEV).float() / D))
+    ang = torch.arange(max_len, device=DEV).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+
+    ref = torch.empty(M, 3 * hd, dtype=torch.bfloat16, device=DEV)
+    kc0 = torch.zeros(3, H, max_len, D, dtype=torch.bfloat16, device=DEV)
+    vc0 = torch.zeros_like(kc0)
+    B.gemm(x, w, ref, bias=bias, tile=3)
+    B.rope_kv(ref, hd, 2 * hd, cos, sin, pos, sid, kc0, vc0, H, D, max_len)
+
+    out = torch.full((M + 3, 3 * hd), 7.0, dtype=torch.bfloat16, device=DEV)   # 3 guard rows below the matrix
+    kc1, vc1 = torch.zeros_like(kc0), torch.zeros_like(kc0)
+    B.gemm(x, w, out, bias=bias, tile=3, M=M, rope=(hd, 2 * hd, cos, sin, pos, sid, kc1, vc1, H, D, max_len))
+    assert torch.equal(out[:M], ref)
+    assert torch.equal(out[M:], torch.full((3, 3 * hd), 7.0, dtype=torch.bfloat16, device=DEV))
+    assert torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
+    # and without a cache (training-style forward): rows only
+    out2 = torch.empty(M, 3 * hd, dtype=torch.bfloat16, device=DEV)
+    B.gemm(x, w, out2, bias=bias, tile=3, rope=(hd, 2 * hd, cos, sin, pos, None, None, None, H, D, max_len))
+    assert torch.equal(out2, ref)
+
+
+def test_gemm_rope_kv_rejects_unfusable(B):
+    H, D, K = 3, 128, 256          # 384 columns per block: not a multiple of the 256-column tile
+    x, w = _rand_bf16(300, K, seed=53), _rand_bf16(3 * H * D, K, seed=54)
+    out = torch.empty(300, 3 * H * D, dtype=torch.bfloat16, device=DEV)
+    cs = torch.zeros(8, D // 2, device=DEV)
+    pos = torch.zeros(300, dtype=torch.int32, device=DEV)
+    assert not B.rope_fusable(300, H, D, K)
+    with pytest.raises(RuntimeError, match="icl_gemm_rope_kv_bf16"):
+        B.gemm(x, w, out, tile=3, rope=(H * D, 2 * H * D, cs, cs, pos, None, None, None, H, D, 8))
+
+
 def test_embed_gather_interleave(B):
     V, Hd = 300, 512
     table = _rand_bf16(V, Hd, seed=42)
