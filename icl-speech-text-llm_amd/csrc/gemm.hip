@@ -14,6 +14,7 @@
 // Tiles: 128x128 (2x2 waves, 4x4 MFMA tiles per wave) for prefill/encoder shapes,
 //        64x64   (2x2 waves, 2x2 MFMA tiles per wave) for skinny / decode shapes (+ split-K).
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -971,6 +972,204 @@ int launch_skinny(GemmParams& p, hipStream_t stream) {
   return ICL_OK;
 }
 
+// =================================================================================================================
+// Decode GEMM for 64 < M <= 128 (tile id 5).  At this size a decode GEMM sits on the ridge: 2*128 FLOP per weight
+// byte, i.e. the 13.5 GB of Llama-7B weights cost about the same on the matrix pipe as on HBM, and what decides is how
+// much a CU has to move per weight byte: through its vector-memory path (measured ceiling here ~55-68 GB/s per CU) and
+// out of LDS (128 B/clk).  The 64x64 LDS tile moves 3 bytes per weight byte (W once, the activation slice twice as
+// much again from L2) and reads 4 bytes of LDS; this kernel moves 2 and reads 4 — but of a tile twice as wide:
+//   * one block = ALL (<= 128) rows x 128 columns.  Its 8 waves are 4 column groups (32 columns = two 16-wide n-tiles,
+//     so a SwiGLU gate block and its up block meet in one lane) x 2 K-halves: wave (wc, wk) takes the 32-wide k-step
+//     wk of every 64-wide K-tile.  Every weight byte is loaded by exactly one wave, and each wave reads only its half
+//     of the staged activations (splitting the columns 8 ways instead would have every wave read all of them: LDS-bound
+//     at 0.59 us per K-tile).  The two K-halves meet once, through LDS, after the loop (fixed order: even + odd);
+//   * W goes HBM -> VGPR directly in MFMA operand order from the decode-packed copy (icl_pack_decode_weights): per
+//     16-row n-tile a K-long stream of 1-KB pieces, one per 32-wide k-step, so a wave-load is 1 KB contiguous, lane l
+//     at byte 16*l.  (Row-major W read in operand order is 16 rows x 64 B per wave-load = 64 separate L1 accesses; that
+//     pattern capped the first version of this kernel and caps the skinny kernel.)  DEPTH K-tiles deep in registers;
+//   * A (shared by all waves) is staged by LDS-DMA into a DEPTH+1 ring, one barrier per K-tile;
+//   * loads past the end of the K range are clamped to its last tile, so the in-flight count (vmcnt) is the same in
+//     every iteration and no tail code exists;
+//   * split-K over grid.z with the same workspace slabs + reduce kernel as the other tiles; with split_k == 1 the bias
+//     is folded into the accumulator init like everywhere else.
+template <int DEPTH>   // DEPTH: K-tiles of W in registers (and of A in LDS, + 1 being read)
+__global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
+  constexpr int NI = 2, BN = 4 * NI * 16, A_STAGE = 128 * 128, NSA = DEPTH + 1, G = 2 + NI;   // G: VMEM loads per K-tile per lane
+  static_assert(NSA * A_STAGE >= 4 * 8 * NI * 1024, "the K-half exchange reuses the A ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 3, wk = wave >> 2;
+  const int n0 = blockIdx.x * BN, z = blockIdx.z;
+  const int nk = p.K >> 6;
+  int kt0 = 0, kt1 = nk;
+  if (p.split_k > 1) {
+    kt0 = (int)(((int64_t)z * nk) / p.split_k);
+    kt1 = (int)(((int64_t)(z + 1) * nk) / p.split_k);
+  }
+  const int nt = kt1 - kt0;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const __bf16* ga[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (j * 8 + wave) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    ga[j] = p.A + (int64_t)min(row, p.M - 1) * p.lda + (int64_t)kt0 * 64 + chunk * 8;
+  }
+  const int n_tiles16 = (p.N + 15) >> 4;
+  const __bf16* gw[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+    gw[j] = p.W + ((int64_t)min((n0 >> 4) + wc * NI + j, n_tiles16 - 1) * (p.K >> 5) + (int64_t)kt0 * 2 + wk) * 512 + lane * 8;
+
+  auto stage_a = [&](int t, int slot) {
+    const int tc = min(t, nt - 1);
+    char* base = smem + slot * A_STAGE + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)(ga[0] + (int64_t)tc * 64), (lptr_t)base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(ga[1] + (int64_t)tc * 64), (lptr_t)(base + 8 * 1024), 16, 0, 0);
+  };
+  bf16x8 wf[DEPTH][NI];
+  auto load_w = [&](bf16x8 (&w)[NI], int t) {
+    const int tc = min(t, nt - 1);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      // raw loads: hipcc's waitcnt pass answers a loop-carried register load next to LDS-DMA with vmcnt(0) at the loop
+      // header (the whole prefetch drained once per unrolled body); the counted wait in tile() covers these instead
+      const __bf16* src = gw[j] + (int64_t)tc * 1024;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[j]) : "v"(src) : "memory");
+    }
+  };
+  const int a_off = fr * 128 + (((wk * 4 + fq) ^ (fr >> 1)) * 16);
+
+  f32x4 acc[8][NI];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // bias folded into the accumulator init exactly like the LDS tiles do ((bias + sum), residual last); K-half 0 carries it
+  const bool fold_bias = p.split_k == 1 && vec_path_ok(p) && (p.epi & ICL_EPI_BIAS);
+  if (fold_bias && wk == 0) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + (wc * NI + j) * 16 + fq * 4;
+      const f32x4 b4 = n < p.N ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i][j] = b4;
+    }
+  }
+
+  int slot = 0;                              // ring slot of the K-tile being computed
+  auto tile = [&](bf16x8 (&w)[NI], int t) {
+    // the K-tile t operands are the oldest loads in flight; tiles t+1 .. t+DEPTH-1 (G loads each) may still be
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * G) : "memory");
+    __builtin_amdgcn_s_barrier();            // A(t) of every wave has landed; every wave is done reading A(t-1)
+    __builtin_amdgcn_sched_barrier(0);
+    stage_a(t + DEPTH, slot == 0 ? NSA - 1 : slot - 1);   // into the ring slot of t-1
+    const char* a_s = smem + slot * A_STAGE + a_off;
+    slot = slot == NSA - 1 ? 0 : slot + 1;
+    bf16x8 af[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(a_s + i * 16 * 128);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(w, t + DEPTH);                    // this register set is free again
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    stage_a(d, d);
+    load_w(wf[d], d);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int t = 0;
+  for (; t + DEPTH <= nt; t += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) tile(wf[d], t + d);
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d)
+    if (t + d < nt) tile(wf[d], t + d);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped over-issue must not outlive the block's LDS
+  // ... nor its registers: to the compiler a raw load's result is there at once, so a result nobody reads is a free
+  // register while the load is still in flight.  Reading every set here keeps all of them allocated up to the wait.
+#pragma unroll
+  for (int s_ = 0; s_ < DEPTH; ++s_)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wf[s_][j]));
+
+  // ---- the two K-halves meet: odd half -> LDS (the A ring is dead), even half adds it on top and stores ---------------
+  __syncthreads();
+  char* xbase = smem + wc * (8 * NI * 1024) + lane * 16;
+  if (wk == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) *(f32x4*)(xbase + (i * NI + j) * 1024) = acc[i][j];
+  }
+  __syncthreads();
+  if (wk == 1) return;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = acc[i][j] + *(const f32x4*)(xbase + (i * NI + j) * 1024);
+
+  // ---- epilogue: acc[i][j][r] = C[m][n], m = i*16 + fr, n = n0 + (wc*NI + j)*16 + fq*4 + r ---------------------------
+  GemmParams q = p;
+  if (fold_bias) q.epi &= ~ICL_EPI_BIAS;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int nt_ = n0 + (wc * NI + j) * 16;
+      if (p.split_k > 1) {
+        epi_store_partial(p, z, m, nt_ + fq * 4, acc[i][j]);
+      } else if (p.epi & ICL_EPI_SWIGLU) {
+        if ((j & 1) == 0) epi_store_swiglu(q, 0, m, nt_, fq * 4, acc[i][j], acc[i][(j + 1) % NI]);
+      } else {
+        epi_store4(q, 0, m, nt_ + fq * 4, acc[i][j]);
+      }
+    }
+  }
+}
+
+// row-major W [N][ldw] -> decode-packed: piece (n-tile, k-step, lane = fq*16 + fr) holds W[16*nt + fr][32*ks + 8*fq .. +8]
+__global__ __launch_bounds__(256) void pack_decode_w_kernel(const unsigned short* W, int64_t ldw, int N, int K, u32x4* out) {
+  const int64_t pieces = (int64_t)((N + 15) >> 4) * (K >> 5) * 64;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < pieces; q += (int64_t)gridDim.x * 256) {
+    const int l = (int)(q & 63);
+    const int64_t blk = q >> 6;
+    const int ks = (int)(blk % (K >> 5));
+    const int64_t row = (blk / (K >> 5)) * 16 + (l & 15);
+    out[q] = row < N ? *(const u32x4*)(W + row * ldw + ks * 32 + (l >> 4) * 8) : u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
+template <int DEPTH>
+int launch_m128(GemmParams& p, hipStream_t stream) {
+  constexpr int BN = 128, SMEM = (DEPTH + 1) * 128 * 128;
+  auto kern = gemm_m128_kernel<DEPTH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) {
+      icl_set_error("icl_gemm_bf16: hipFuncSetAttribute(%d) failed: %s", SMEM, hipGetErrorString(e));
+      return ICL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((p.N + BN - 1) / BN, 1, p.split_k), dim3(512), SMEM, stream, p);
+  ICL_CHECK_LAUNCH("icl_gemm_bf16(m128)");
+  return ICL_OK;
+}
+
 template <int WAVES_M, int WAVES_N, int MI, int NI>
 int launch_tile(GemmParams& p, int batch, hipStream_t stream) {
   constexpr int BM = WAVES_M * MI * 16, BN = WAVES_N * NI * 16;
@@ -1097,6 +1296,10 @@ static int gemm_impl(const icl_gemm_args* a, void* stream_, const RopeFuse* rope
     if (sw) rc = mb <= 1 ? launch_skinny<1, 2, 4>(p, stream) : mb == 2 ? launch_skinny<2, 2, 2>(p, stream) : launch_skinny<4, 2, 2>(p, stream);
     else    rc = mb <= 1 ? launch_skinny<1, 1, 8>(p, stream) : mb == 2 ? launch_skinny<2, 1, 4>(p, stream) : launch_skinny<4, 1, 2>(p, stream);
     return rc;
+  } else if (tile == 5) {
+    ICL_CHECK_ARG(a->M <= 128 && a->batch == 1, "icl_gemm_bf16: the decode tile needs M <= 128 and batch == 1");
+    // 256-column blocks when that still gives every CU most of a block, 128-column blocks otherwise
+    rc = launch_m128<3>(p, stream);   // depth 3 / 4 / 6 measured alike: the CU's vector-memory path is the limit, not latency
   } else {
     icl_set_error("icl_gemm_bf16: unsupported tile id %d", tile);
     return ICL_EINVAL;
@@ -1137,4 +1340,15 @@ extern "C" int icl_gemm_rope_kv_bf16(const icl_gemm_args* a, int64_t k_off, int6
   rf.kc = (unsigned short*)kcache; rf.vc = (unsigned short*)vcache;
   rf.k_off = (int)k_off; rf.v_off = (int)v_off; rf.H = n_heads; rf.max_len = max_len;
   return gemm_impl(a, stream, &rf);
+}
+
+extern "C" int icl_pack_decode_weights(const void* W, int64_t ldw, int32_t N, int32_t K, void* out, void* stream) {
+  ICL_CHECK_ARG(W && out && N > 0 && K > 0, "icl_pack_decode_weights: bad arguments");
+  ICL_CHECK_ARG(K % 64 == 0 && ldw % 8 == 0 && ldw >= K, "icl_pack_decode_weights: K=%d must be a multiple of 64, ldw=%lld a multiple of 8", K, (long long)ldw);
+  ICL_CHECK_ARG(((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 15) == 0, "icl_pack_decode_weights: misaligned pointer");
+  const int64_t pieces = (int64_t)((N + 15) >> 4) * (K >> 5) * 64;
+  const int blocks = (int)std::min<int64_t>((pieces + 255) / 256, 65535);
+  hipLaunchKernelGGL(pack_decode_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)W, ldw, N, K, (u32x4*)out);
+  ICL_CHECK_LAUNCH("icl_pack_decode_weights");
+  return ICL_OK;
 }

@@ -69,6 +69,7 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "icl_gemm_rope_kv_bf16": (c_int, [POINTER(GemmArgs), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "icl_pack_decode_weights": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "icl_embed_gather_interleave": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                             c_int32, c_int32, c_void_p]),
     "icl_argmax_eos": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
@@ -156,7 +157,7 @@ def _require_gpu(*tensors):
 # ------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, residual=None, gelu=False,
          swiglu=False, split_k: int = 1, workspace=None, tile: int = 0, M=None, K=None, lda=None,
-         batch: int = 1, stride_a: int = 0, stride_c: int = 0, stride_r: int = 0, rope=None) -> torch.Tensor:
+         batch: int = 1, stride_a: int = 0, stride_c: int = 0, stride_r: int = 0, rope=None, N=None) -> torch.Tensor:
     """out = epilogue(a @ w.T).  a: bf16 [M,K] (row stride lda), w: bf16 [N,K], out: bf16|f32 [M,N'].
 
     ``rope`` = (k_off, v_off, cos, sin, pos, seq_ids, kcache, vcache, n_heads, head_dim, max_len) runs the QKV projection
@@ -164,7 +165,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, resi
     _require_gpu(a, w, out, bias, residual, workspace)
     lib = load_library()
     g = GemmArgs()
-    N = w.shape[0]
+    N = w.shape[0] if N is None else N      # tile 5 takes the decode-packed copy (rows padded to 16): pass the true N
     g.A, g.W, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     g.bias, g.R, g.workspace = _ptr(bias), _ptr(residual), _ptr(workspace)
     g.lda = a.stride(-2) if lda is None else lda
@@ -214,6 +215,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, resi
         GEMM_PROFILE.append((tile, split_k, 2.0 * g.M * N * g.K * batch, e0, e1, (g.M, N, g.K, batch)))
         return out
     launch()
+    return out
+
+
+def pack_decode_weights(w: torch.Tensor, K=None) -> torch.Tensor:
+    """Decode-packed copy of a row-major bf16 weight [N, >=K] for ``gemm(..., tile=5, N=N)`` (icl_pack_decode_weights)."""
+    _require_gpu(w)
+    assert w.dtype == torch.bfloat16 and w.dim() == 2
+    N, K = w.shape[0], (w.shape[1] if K is None else K)
+    out = torch.empty((N + 15) // 16 * 16, K, dtype=torch.bfloat16, device=w.device)
+    _check(load_library().icl_pack_decode_weights(w.data_ptr(), w.stride(0), N, K, out.data_ptr(), _stream()),
+           "icl_pack_decode_weights")
     return out
 
 

@@ -314,6 +314,8 @@ class SpeechQFormerHIP:
 # K9 + K10 + K11 (+K12 host side): Llama
 # ================================================================================================
 class LlamaHIP:
+    decode_tile_m128 = True     # 64 < micro-batch <= 128: the M <= 128 decode tile on decode-packed weight copies
+
     def __init__(self, w: PackedLlama, device):
         self.w = w
         self.device = torch.device(device)
@@ -352,13 +354,18 @@ class LlamaHIP:
             B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, tile=3,
                    rope=(hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len))
         else:
-            B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1), workspace=wsk, tile=sk.get("tile", 0))
+            B.gemm(xn, L.decode_packed[0] if sk.get("tile") == 5 else L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1),
+                   workspace=wsk, tile=sk.get("tile", 0), N=3 * hd, K=w.k_aug)
             B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
         attn_fn(qkv, att)
-        B.gemm(att, L.wo, h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=sk.get("tile", 0))
+        dp = L.decode_packed if sk.get("tile") == 5 else None    # (wqkv, wo, wgu, wdown) in the decode tile's layout
+        B.gemm(att, dp[1] if dp else L.wo, h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=sk.get("tile", 0),
+               N=hd, K=hd)
         B.rmsnorm(h, L.rms2, xn, c.rms_eps, N=hd)
-        B.gemm(xn, L.wgu, act, swiglu=True, K=hd, split_k=sk.get("gu", 1), workspace=wsk, tile=sk.get("tile", 0))
-        B.gemm(act, L.wdown, h, residual=h, split_k=sk.get("down", 1), workspace=wsk, tile=sk.get("tile", 0))
+        B.gemm(xn, dp[2] if dp else L.wgu, act, swiglu=True, K=hd, split_k=sk.get("gu", 1), workspace=wsk,
+               tile=sk.get("tile", 0), N=2 * I)
+        B.gemm(act, dp[3] if dp else L.wdown, h, residual=h, split_k=sk.get("down", 1), workspace=wsk,
+               tile=sk.get("tile", 0), N=hd, K=I)
 
     # ---- K10: prefill over ragged packed sequences ------------------------------------------------
     def prefill(self, ws: Workspace, h: torch.Tensor, seq_lens: List[int], cache: Optional["KVCache"] = None) -> torch.Tensor:
@@ -409,8 +416,19 @@ class LlamaHIP:
             tiles = ((N + 63) // 64) * ((Bn + 63) // 64)
             s = max(1, min(K // 512, (2 * self.n_cu + tiles - 1) // tiles))
             return min(s, 16)
+        def sk5(N, K):          # decode tile: 128-column blocks, about one per CU
+            return max(1, min(self.n_cu // ((N + 127) // 128), K // 512))
         if Bn <= 8:
             split = dict(tile=4)
+        elif 64 < Bn <= 128 and self.decode_tile_m128:
+            # the M <= 128 decode tile on decode-packed copies of the layer weights (made once, on the first such step: a
+            # second 12.9 GB for Llama-2-7B; the prefill kernels keep the row-major originals).  167 -> 132 us per layer.
+            for L in self.w.layers:
+                if getattr(L, "decode_packed", None) is None:
+                    L.decode_packed = (B.pack_decode_weights(L.wqkv, K=self.w.k_aug), B.pack_decode_weights(L.wo, K=c.hidden),
+                                       B.pack_decode_weights(L.wgu, K=c.hidden), B.pack_decode_weights(L.wdown, K=c.ffn))
+            split = dict(qkv=sk5(3 * c.hidden, self.w.k_aug), o=sk5(c.hidden, c.hidden), gu=sk5(2 * c.ffn, c.hidden),
+                         down=sk5(c.hidden, c.ffn), tile=5)
         else:
             split = dict(qkv=sk(3 * c.hidden, self.w.k_aug), o=sk(c.hidden, c.hidden), gu=sk(2 * c.ffn, c.hidden),
                          down=sk(c.hidden, c.ffn), tile=2)

@@ -263,6 +263,7 @@ class LlamaLayer:
     rms2: torch.Tensor
     wgu: torch.Tensor            # [2*ffn, h] interleaved in blocks of 16
     wdown: torch.Tensor
+    decode_packed: Optional[tuple] = None   # (wqkv, wo, wgu, wdown) in the M <= 128 decode tile's layout, made on first use
 
 
 @dataclass

@@ -88,10 +88,17 @@ typedef struct icl_gemm_args {
   int32_t res_dtype;    /* ICL_BF16 | ICL_F32              */
   int32_t split_k;      /* >= 1                            */
   int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (+ split_k), 3 = 256x256 (no split_k), 4 = decode
-                           skinny kernel (M <= 64, batch 1: weights streamed HBM->VGPR, in-block split-K) */
+                           skinny kernel (M <= 64, batch 1: weights streamed HBM->VGPR, in-block split-K),
+                           5 = decode tile for M <= 128 (batch 1, + split_k): W must be the decode-packed copy
+                           made by icl_pack_decode_weights (ldw is ignored)                        */
 } icl_gemm_args;
 
 int icl_gemm_bf16(const icl_gemm_args* args, void* stream);
+/* Decode-packed copy of a weight matrix for tile 5: row-major bf16 W [N][ldw] -> out, (ceil(N/16)*16) x K bf16
+ * elements: per 16-row block a K-long stream of 1-KB pieces (one per 32-wide k-step) in MFMA operand order, so that the
+ * decode kernel's wave-loads are 1 KB contiguous (rows >= N are zero).  A layout copy made once at load time (the
+ * prefill kernels keep reading the row-major original: HBM is sized for both); no reference counterpart. */
+int icl_pack_decode_weights(const void* W, int64_t ldw, int32_t N, int32_t K, void* out, void* stream);
 /* The tile id (1|2|3) that tile == 0 resolves to for this problem (pure host function). */
 int icl_gemm_select_tile(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t split_k);
 

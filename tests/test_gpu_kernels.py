@@ -576,6 +576,42 @@ def test_gemm_skinny_swiglu(B, M):
     assert _relerr(out, ref) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K,split", [(128, 512, 4160, 1), (128, 4096, 1024, 4), (65, 768, 64, 1), (100, 200, 576, 3),
+                                         (97, 12288, 192, 1), (128, 8192, 2048, 5), (77, 264, 320, 5)])
+def test_gemm_m128_decode_kernel(B, M, N, K, split):
+    """Decode tile for 64 < M <= 128 (decode-packed weights HBM -> VGPR, activations through an LDS ring): ragged M and N,
+    K ranges shorter than the prefetch depth, split-K with uneven slices, f32 + bias + residual and bf16 outputs."""
+    a, w = _rand_bf16(M, K, seed=61, scale=0.5), _rand_bf16(N, K, seed=62, scale=0.05)
+    bias, res = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV)
+    ws = torch.empty(split * M * N, device=DEV) if split > 1 else None
+    wp = B.pack_decode_weights(w)
+    out = torch.full((M + 2, N), float("nan"), dtype=torch.float32, device=DEV)
+    B.gemm(a, wp, out, bias=bias, residual=res, tile=5, split_k=split, workspace=ws, M=M, N=N)
+    ref = a.float() @ w.float().t() + bias + res
+    assert (out[:M] - ref).abs().max().item() <= 2e-3
+    assert torch.isnan(out[M:]).all()
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    B.gemm(a, wp, out16, tile=5, split_k=split, workspace=ws, N=N)
+    assert _relerr(out16, a.float() @ w.float().t()) < 4e-3
+    # against the 64x64 tile at the same split: same products, but each slice is summed as (even k-steps) + (odd k-steps)
+    out2 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    B.gemm(a, w, out2, bias=bias, residual=res, tile=2, split_k=split, workspace=ws)
+    assert (out[:M] - out2).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("M,split", [(128, 1), (90, 2)])
+def test_gemm_m128_swiglu(B, M, split):
+    I, K = 11008 // 4, 512
+    a = _rand_bf16(M, K, seed=63, scale=0.5)
+    wg, wu = _rand_bf16(I, K, seed=64, scale=0.1), _rand_bf16(I, K, seed=65, scale=0.1)
+    w = torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+    ws = torch.empty(split * M * 2 * I, device=DEV) if split > 1 else None
+    out = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    B.gemm(a, B.pack_decode_weights(w), out, swiglu=True, tile=5, split_k=split, workspace=ws, N=2 * I)
+    ref = torch.nn.functional.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
+    assert _relerr(out, ref) < 4e-3
+
+
 def _sample_case(logits, prev, step, temp, k, p, pen, u, eos=-1, pad=0, finished=None):
     from icl_speech_text_llm_amd.runtime import binding as Bd
     Bn, V = logits.shape
