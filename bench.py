@@ -223,13 +223,13 @@ def main():
         wavs.append(torch.from_numpy(w).to(dev))
     gathered = torch.empty(world * Bm, NEW_TOKENS, dtype=torch.int32, device=dev) if world > 1 else None
 
-    def step(s):
+    def step(s, gather=True):
         if is_qwen:
             speech, _ = rt.encode_audio(raw_wav=wavs[s], wav_lens=lens)
         else:
             speech = rt.encode_speech(wavs[s], lens)
         res = rt.generate(prompts[s], speech, max_new_tokens=NEW_TOKENS, suppress_eos=True)
-        if world > 1:
+        if world > 1 and gather:
             dist.all_gather_into_tensor(gathered, rt.ws.get("gen_tokens", (Bm, NEW_TOKENS), torch.int32))
         return res.tokens
 
@@ -308,7 +308,7 @@ def main():
         marks = {k: torch.cuda.Event(enable_timing=True) for k in ("enc_start", "prefill_start", "prefill_end", "decode_end")}
         rt.phase_marks = marks
         marks["enc_start"].record()
-        step(total_steps - 1)
+        step(total_steps - 1, gather=False)      # rank 0 only: no collective in here
         torch.cuda.synchronize()
         rt.phase_marks = None
         t_enc = marks["enc_start"].elapsed_time(marks["prefill_start"]) * 1e-3      # front-ends, encoders, Q-Former, prompt gather
