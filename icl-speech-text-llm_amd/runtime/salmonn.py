@@ -153,7 +153,9 @@ class CausalLMRuntimeMixin:
         if sampled:
             knobs = ((float(temperature), int(top_k), float(top_p)) if do_sample else (1.0, 1, 1.0)) + (float(repetition_penalty),)
             uni = ws.get("gen_uniform", (max_new_tokens, Bn), F32)
-            if do_sample:
+            if do_sample and generator is not None and generator.device.type != uni.device.type:
+                uni.copy_(torch.rand(uni.shape, generator=generator))      # a host generator: draw there, same stream of uniforms
+            elif do_sample:
                 uni.uniform_(0.0, 1.0, generator=generator)
             else:
                 uni.zero_()

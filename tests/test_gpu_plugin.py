@@ -125,6 +125,26 @@ def test_cli_end_to_end(tmp_path):
     assert len(res) == 6 and set(res[0]) == {"text", "true_label", "predicted_label (cleaned)", "predicted_label", "dataset_type"}
 
 
+def test_interactive_inference_text_query(monkeypatch, capsys):
+    """inference/interactive_inference.py (reference :171-281): a text-only query goes through process_inputs -> one-item
+    collate_batch -> generate_output with do_sample at --temperature; same seed -> same text; the prompt loop ends on 'exit'."""
+    from icl_speech_text_llm_amd.inference import interactive_inference as ii
+    args = ii.parse_args(["--arch", "tiny", "--device", "cuda", "--max_new_tokens", "12", "--temperature", "0.7", "--seed", "5",
+                          "--query", "What is the definition of positive?"])
+    model, processor = ii.setup_model(args)
+    a = ii.run_interactive_inference(model, processor, args.query, args)
+    b = ii.run_interactive_inference(model, processor, args.query, args)
+    assert isinstance(a, str) and a == b
+    args.seed = 6
+    c = ii.run_interactive_inference(model, processor, "What is the definition of negative?", args)
+    assert isinstance(c, str)
+    feed = iter(["What is neutral?", "exit"])
+    monkeypatch.setattr("builtins.input", lambda *_: next(feed))
+    monkeypatch.setattr(ii, "setup_model", lambda _args: (model, processor))
+    rc = ii.main(["--arch", "tiny", "--device", "cuda", "--max_new_tokens", "4", "--seed", "1", "--query", "hello"])
+    assert rc == 0 and capsys.readouterr().out.count("Model output:") == 2
+
+
 def _sqa_batch(model, root, fewshot_mode, num_examples, bs=2):
     import random
     from icl_speech_text_llm_amd.data.dataset_factory import DatasetFactory
