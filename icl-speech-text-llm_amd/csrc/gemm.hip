@@ -886,7 +886,7 @@ int launch_tile256(GemmParams& p, int batch, hipStream_t stream, const RopeFuse*
 // (M x K, <= 0.7 MB) are re-read by every block from L2.  MB = 16-row blocks of M, NT = 16-column tiles per block
 // (2 for the SwiGLU epilogue so a gate block and its up block meet in one lane).
 // =================================================================================================================
-template <int MB, int NT, int U>
+template <int MB, int NT, int U, bool PACKED>   // PACKED: W is the decode-packed copy (tile 6): a wave-load is 1 KB contiguous
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmParams p) {
   __shared__ float red[8][NT][MB][256];   // [wave][n-tile][m-block][lane*4 + r]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -898,7 +898,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmParams p) {
 
   const __bf16* wp[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) wp[t] = p.W + (int64_t)min(n0 + t * 16 + fr, p.N - 1) * p.ldw + fq * 8;
+  for (int t = 0; t < NT; ++t)
+    wp[t] = PACKED ? p.W + (int64_t)min((n0 >> 4) + t, ((p.N + 15) >> 4) - 1) * (p.K >> 5) * 512 + lane * 8
+                   : p.W + (int64_t)min(n0 + t * 16 + fr, p.N - 1) * p.ldw + fq * 8;
+  constexpr int WSTEP = PACKED ? 512 : 32;   // elements between consecutive 32-wide k-steps of one n-tile
   const __bf16* ap[MB];
 #pragma unroll
   for (int b = 0; b < MB; ++b) ap[b] = p.A + (int64_t)min(b * 16 + fr, p.M - 1) * p.lda + fq * 8;
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmParams p) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wf[u][t] = *(const bf16x8*)(wp[t] + (int64_t)(s + u) * 32);
+      for (int t = 0; t < NT; ++t) wf[u][t] = *(const bf16x8*)(wp[t] + (int64_t)(s + u) * WSTEP);
 #pragma unroll
       for (int b = 0; b < MB; ++b) af[u][b] = *(const bf16x8*)(ap[b] + (int64_t)(s + u) * 32);
     }
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmParams p) {
   for (; s < s1; ++s) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const bf16x8 wf = *(const bf16x8*)(wp[t] + (int64_t)s * 32);
+      const bf16x8 wf = *(const bf16x8*)(wp[t] + (int64_t)s * WSTEP);
 #pragma unroll
       for (int b = 0; b < MB; ++b) {
         const bf16x8 af = *(const bf16x8*)(ap[b] + (int64_t)s * 32);
@@ -965,9 +968,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmParams p) {
 }
 
 template <int MB, int NT, int U>
-int launch_skinny(GemmParams& p, hipStream_t stream) {
+int launch_skinny(GemmParams& p, hipStream_t stream, bool packed) {
   const int blocks = (p.N + 16 * NT - 1) / (16 * NT);
-  hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U>), dim3(blocks), dim3(512), 0, stream, p);
+  if (packed) hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, true>), dim3(blocks), dim3(512), 0, stream, p);
+  else        hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, false>), dim3(blocks), dim3(512), 0, stream, p);
   ICL_CHECK_LAUNCH("icl_gemm_bf16(skinny)");
   return ICL_OK;
 }
@@ -992,10 +996,12 @@ int launch_skinny(GemmParams& p, hipStream_t stream) {
 //     every iteration and no tail code exists;
 //   * split-K over grid.z with the same workspace slabs + reduce kernel as the other tiles; with split_k == 1 the bias
 //     is folded into the accumulator init like everywhere else.
-template <int DEPTH>   // DEPTH: K-tiles of W in registers (and of A in LDS, + 1 being read)
+template <int DEPTH, int MT>   // DEPTH: K-tiles of W in registers (and of A in LDS, + 1 being read); MT: 16-row tiles (8 | 4)
 __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
-  constexpr int NI = 2, BN = 4 * NI * 16, A_STAGE = 128 * 128, NSA = DEPTH + 1, G = 2 + NI;   // G: VMEM loads per K-tile per lane
-  static_assert(NSA * A_STAGE >= 4 * 8 * NI * 1024, "the K-half exchange reuses the A ring");
+  constexpr int NI = 2, BN = 4 * NI * 16, A_INSTR = MT / 4, A_STAGE = MT * 16 * 128, NSA = DEPTH + 1;
+  constexpr int G = A_INSTR + NI;   // VMEM loads per K-tile per lane
+  static_assert(MT == 8 || MT == 4, "128- or 64-row blocks");
+  static_assert(NSA * A_STAGE >= 4 * MT * NI * 1024, "the K-half exchange reuses the A ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1010,9 +1016,9 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
   const int nt = kt1 - kt0;
   const int fr = lane & 15, fq = lane >> 4;
 
-  const __bf16* ga[2];
+  const __bf16* ga[A_INSTR];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < A_INSTR; ++j) {
     const int row = (j * 8 + wave) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     ga[j] = p.A + (int64_t)min(row, p.M - 1) * p.lda + (int64_t)kt0 * 64 + chunk * 8;
@@ -1026,8 +1032,9 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
   auto stage_a = [&](int t, int slot) {
     const int tc = min(t, nt - 1);
     char* base = smem + slot * A_STAGE + wave * 1024;
-    __builtin_amdgcn_global_load_lds((gptr_t)(ga[0] + (int64_t)tc * 64), (lptr_t)base, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(ga[1] + (int64_t)tc * 64), (lptr_t)(base + 8 * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ga[j] + (int64_t)tc * 64), (lptr_t)(base + j * 8 * 1024), 16, 0, 0);
   };
   bf16x8 wf[DEPTH][NI];
   auto load_w = [&](bf16x8 (&w)[NI], int t) {
@@ -1042,9 +1049,9 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
   };
   const int a_off = fr * 128 + (((wk * 4 + fq) ^ (fr >> 1)) * 16);
 
-  f32x4 acc[8][NI];
+  f32x4 acc[MT][NI];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -1056,7 +1063,7 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
       const int n = n0 + (wc * NI + j) * 16 + fq * 4;
       const f32x4 b4 = n < p.N ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i][j] = b4;
+      for (int i = 0; i < MT; ++i) acc[i][j] = b4;
     }
   }
 
@@ -1069,11 +1076,11 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
     stage_a(t + DEPTH, slot == 0 ? NSA - 1 : slot - 1);   // into the ring slot of t-1
     const char* a_s = smem + slot * A_STAGE + a_off;
     slot = slot == NSA - 1 ? 0 : slot + 1;
-    bf16x8 af[8];
+    bf16x8 af[MT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(a_s + i * 16 * 128);
+    for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(a_s + i * 16 * 128);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], af[i], acc[i][j], 0, 0, 0);
@@ -1106,17 +1113,17 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
 
   // ---- the two K-halves meet: odd half -> LDS (the A ring is dead), even half adds it on top and stores ---------------
   __syncthreads();
-  char* xbase = smem + wc * (8 * NI * 1024) + lane * 16;
+  char* xbase = smem + wc * (MT * NI * 1024) + lane * 16;
   if (wk == 1) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) *(f32x4*)(xbase + (i * NI + j) * 1024) = acc[i][j];
   }
   __syncthreads();
   if (wk == 1) return;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = acc[i][j] + *(const f32x4*)(xbase + (i * NI + j) * 1024);
 
@@ -1124,7 +1131,7 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
   GemmParams q = p;
   if (fold_bias) q.epi &= ~ICL_EPI_BIAS;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < MT; ++i) {
     const int m = i * 16 + fr;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -1152,10 +1159,10 @@ __global__ __launch_bounds__(256) void pack_decode_w_kernel(const unsigned short
   }
 }
 
-template <int DEPTH>
+template <int DEPTH, int MT>
 int launch_m128(GemmParams& p, hipStream_t stream) {
-  constexpr int BN = 128, SMEM = (DEPTH + 1) * 128 * 128;
-  auto kern = gemm_m128_kernel<DEPTH>;
+  constexpr int BN = 128, SMEM = (DEPTH + 1) * MT * 16 * 128;
+  auto kern = gemm_m128_kernel<DEPTH, MT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -1288,18 +1295,19 @@ static int gemm_impl(const icl_gemm_args* a, void* stream_, const RopeFuse* rope
   else if (tile == 3) {
     ICL_CHECK_ARG(a->split_k == 1, "icl_gemm_bf16: the 256x256 tile does not support split_k");
     rc = launch_tile256(p, a->batch, stream);
-  } else if (tile == 4) {
+  } else if (tile == 4 || tile == 6) {   // 6: the same kernel on the decode-packed copy of W
     ICL_CHECK_ARG(a->M <= 64 && a->batch == 1, "icl_gemm_bf16: the skinny kernel needs M <= 64 and batch == 1");
     p.split_k = 1;   // K is split inside the block
-    const bool sw = a->epilogue & ICL_EPI_SWIGLU;
+    const bool sw = a->epilogue & ICL_EPI_SWIGLU, pk = tile == 6;
     const int mb = (a->M + 15) / 16;
-    if (sw) rc = mb <= 1 ? launch_skinny<1, 2, 4>(p, stream) : mb == 2 ? launch_skinny<2, 2, 2>(p, stream) : launch_skinny<4, 2, 2>(p, stream);
-    else    rc = mb <= 1 ? launch_skinny<1, 1, 8>(p, stream) : mb == 2 ? launch_skinny<2, 1, 4>(p, stream) : launch_skinny<4, 1, 2>(p, stream);
+    if (sw) rc = mb <= 1 ? launch_skinny<1, 2, 4>(p, stream, pk) : mb == 2 ? launch_skinny<2, 2, 2>(p, stream, pk) : launch_skinny<4, 2, 2>(p, stream, pk);
+    else    rc = mb <= 1 ? launch_skinny<1, 1, 8>(p, stream, pk) : mb == 2 ? launch_skinny<2, 1, 4>(p, stream, pk) : launch_skinny<4, 1, 2>(p, stream, pk);
     return rc;
   } else if (tile == 5) {
     ICL_CHECK_ARG(a->M <= 128 && a->batch == 1, "icl_gemm_bf16: the decode tile needs M <= 128 and batch == 1");
     // 256-column blocks when that still gives every CU most of a block, 128-column blocks otherwise
-    rc = launch_m128<3>(p, stream);   // depth 3 / 4 / 6 measured alike: the CU's vector-memory path is the limit, not latency
+    // depth 3 / 4 / 6 measured alike: the CU's vector-memory path is the limit, not latency.  64-row blocks stage half the A bytes
+    rc = a->M <= 64 ? launch_m128<3, 4>(p, stream) : launch_m128<3, 8>(p, stream);
   } else {
     icl_set_error("icl_gemm_bf16: unsupported tile id %d", tile);
     return ICL_EINVAL;

@@ -314,7 +314,7 @@ class SpeechQFormerHIP:
 # K9 + K10 + K11 (+K12 host side): Llama
 # ================================================================================================
 class LlamaHIP:
-    decode_tile_m128 = True     # 64 < micro-batch <= 128: the M <= 128 decode tile on decode-packed weight copies
+    decode_packed_weights = True     # micro-batch <= 128: decode GEMMs stream decode-packed copies of the layer weights
 
     def __init__(self, w: PackedLlama, device):
         self.w = w
@@ -354,11 +354,11 @@ class LlamaHIP:
             B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, tile=3,
                    rope=(hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len))
         else:
-            B.gemm(xn, L.decode_packed[0] if sk.get("tile") == 5 else L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1),
+            B.gemm(xn, L.decode_packed[0] if sk.get("tile") in (5, 6) else L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1),
                    workspace=wsk, tile=sk.get("tile", 0), N=3 * hd, K=w.k_aug)
             B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
         attn_fn(qkv, att)
-        dp = L.decode_packed if sk.get("tile") == 5 else None    # (wqkv, wo, wgu, wdown) in the decode tile's layout
+        dp = L.decode_packed if sk.get("tile") in (5, 6) else None    # (wqkv, wo, wgu, wdown) in the decode kernels' layout
         B.gemm(att, dp[1] if dp else L.wo, h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=sk.get("tile", 0),
                N=hd, K=hd)
         B.rmsnorm(h, L.rms2, xn, c.rms_eps, N=hd)
@@ -409,26 +409,30 @@ class LlamaHIP:
         Bn = next_ids.numel()
         h = self.embed(ws, next_ids, None, name="dc_h")
         H, D = c.n_heads, c.head_dim
-        # Weights are streamed once per step.  Bn <= 8: the skinny kernel (HBM -> VGPR stream, in-block split-K; 3.5-5.0
-        # TB/s measured with rotating weights vs 2.2-4.3 for the LDS tile).  Larger Bn: 64x64 LDS tile + split-K so that
-        # every GEMM launches >= ~2 blocks per CU.
+        # Weights are streamed once per step, from decode-packed copies of the layer weights (made once, on the first decode
+        # step: a second 12.9 GB for Llama-2-7B — the prefill kernels keep the row-major originals; HBM is sized for both): a
+        # wave-load is 1 KB contiguous instead of 16 rows x 64 B.  Per layer, rotating weights: Bn <= 8 the skinny kernel
+        # (in-block split-K) 90-108 -> 79-87 us (5.1 TB/s at Bn = 1); 9..128 the decode tile (64- or 128-row blocks, about one
+        # block per CU) 115-167 -> 97-132 us; above 128 the 64x64 LDS tile + split-K on the row-major weights.
         def sk(N, K):
             tiles = ((N + 63) // 64) * ((Bn + 63) // 64)
             s = max(1, min(K // 512, (2 * self.n_cu + tiles - 1) // tiles))
             return min(s, 16)
-        def sk5(N, K):          # decode tile: 128-column blocks, about one per CU
+
+        def sk5(N, K):
             return max(1, min(self.n_cu // ((N + 127) // 128), K // 512))
-        if Bn <= 8:
-            split = dict(tile=4)
-        elif 64 < Bn <= 128 and self.decode_tile_m128:
-            # the M <= 128 decode tile on decode-packed copies of the layer weights (made once, on the first such step: a
-            # second 12.9 GB for Llama-2-7B; the prefill kernels keep the row-major originals).  167 -> 132 us per layer.
+        if Bn <= 128 and self.decode_packed_weights:
             for L in self.w.layers:
                 if getattr(L, "decode_packed", None) is None:
                     L.decode_packed = (B.pack_decode_weights(L.wqkv, K=self.w.k_aug), B.pack_decode_weights(L.wo, K=c.hidden),
                                        B.pack_decode_weights(L.wgu, K=c.hidden), B.pack_decode_weights(L.wdown, K=c.ffn))
-            split = dict(qkv=sk5(3 * c.hidden, self.w.k_aug), o=sk5(c.hidden, c.hidden), gu=sk5(2 * c.ffn, c.hidden),
-                         down=sk5(c.hidden, c.ffn), tile=5)
+            if Bn <= 8:
+                split = dict(tile=6)
+            else:
+                split = dict(qkv=sk5(3 * c.hidden, self.w.k_aug), o=sk5(c.hidden, c.hidden), gu=sk5(2 * c.ffn, c.hidden),
+                             down=sk5(c.hidden, c.ffn), tile=5)
+        elif Bn <= 8:
+            split = dict(tile=4)
         else:
             split = dict(qkv=sk(3 * c.hidden, self.w.k_aug), o=sk(c.hidden, c.hidden), gu=sk(2 * c.ffn, c.hidden),
                          down=sk(c.hidden, c.ffn), tile=2)

@@ -89,8 +89,9 @@ typedef struct icl_gemm_args {
   int32_t split_k;      /* >= 1                            */
   int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (+ split_k), 3 = 256x256 (no split_k), 4 = decode
                            skinny kernel (M <= 64, batch 1: weights streamed HBM->VGPR, in-block split-K),
-                           5 = decode tile for M <= 128 (batch 1, + split_k): W must be the decode-packed copy
-                           made by icl_pack_decode_weights (ldw is ignored)                        */
+                           5 = decode tile for M <= 128 (batch 1, + split_k; 64-row blocks when M <= 64): W must
+                           be the decode-packed copy made by icl_pack_decode_weights (ldw is ignored),
+                           6 = the skinny kernel (as 4) on the decode-packed copy                       */
 } icl_gemm_args;
 
 int icl_gemm_bf16(const icl_gemm_args* args, void* stream);

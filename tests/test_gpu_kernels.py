@@ -564,6 +564,18 @@ def test_gemm_skinny_decode_kernel(B, M, N, K):
     assert _relerr(out16, a.float() @ w.float().t()) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 1000, 576), (40, 264, 4160), (64, 2048, 64)])
+def test_gemm_skinny_on_packed_weights_is_bit_identical(B, M, N, K):
+    """tile 6 = the skinny kernel streaming the decode-packed copy: the same MFMAs in the same order as tile 4 on row-major W."""
+    a, w = _rand_bf16(M, K, seed=56, scale=0.5), _rand_bf16(N, K, seed=57, scale=0.05)
+    bias, res = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV)
+    ref = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    B.gemm(a, w, ref, bias=bias, residual=res, tile=4)
+    B.gemm(a, B.pack_decode_weights(w), out, bias=bias, residual=res, tile=6, N=N)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("M", [1, 32, 64])
 def test_gemm_skinny_swiglu(B, M):
     I, K = 11008 // 4, 512
@@ -577,7 +589,8 @@ def test_gemm_skinny_swiglu(B, M):
 
 
 @pytest.mark.parametrize("M,N,K,split", [(128, 512, 4160, 1), (128, 4096, 1024, 4), (65, 768, 64, 1), (100, 200, 576, 3),
-                                         (97, 12288, 192, 1), (128, 8192, 2048, 5), (77, 264, 320, 5)])
+                                         (97, 12288, 192, 1), (128, 8192, 2048, 5), (77, 264, 320, 5),
+                                         (64, 4096, 1024, 2), (9, 520, 576, 1), (33, 1000, 320, 3)])   # 64-row blocks
 def test_gemm_m128_decode_kernel(B, M, N, K, split):
     """Decode tile for 64 < M <= 128 (decode-packed weights HBM -> VGPR, activations through an LDS ring): ragged M and N,
     K ranges shorter than the prefetch depth, split-K with uneven slices, f32 + bias + residual and bf16 outputs."""
