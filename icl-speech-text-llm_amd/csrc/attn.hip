@@ -31,6 +31,7 @@ struct AttnParams {
   const float* rel_bias;
   const float* rel_gate;
   int64_t ldq, ldk, ldv, ldo;
+  int64_t kv_seq_stride, kv_head_stride;   // != 0: K/V live in a [seq][head][pos][D]-style cache (row stride ldk / ldv)
   int n_heads, rel_span, n_qblocks;
   float scale_log2e;
 };
@@ -124,6 +125,11 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
   // crosses the end of the sequence takes the clamped form (rows past the end are masked, the read must stay in bounds).
   auto f_k = [](int row) { return D == 64 ? (row >> 1) & 7 : row & 15; };
   auto f_v = [](int row) { return D == 64 ? ((row >> 1) & 1) << 2 : (row & 3) << 2; };
+  // row 0 of this (sequence, head): packed rows [cu[seq] + j][head*D ..] of the fused QKV buffer, or — when the strides are
+  // given — rows [seq][head][j][..] of a KV cache (the prefill reads back what the QKV GEMM's epilogue appended)
+  const int64_t kv_off = p.kv_seq_stride ? (int64_t)seq * p.kv_seq_stride + (int64_t)head * p.kv_head_stride : -1;
+  const unsigned short* kbase = kv_off >= 0 ? p.K + kv_off : p.K + (int64_t)row0 * p.ldk + head * D;
+  const unsigned short* vbase = kv_off >= 0 ? p.V + kv_off : p.V + (int64_t)row0 * p.ldv + head * D;
   const unsigned short* kptr[NCH];
   const unsigned short* vptr[NCH];
   int srow[NCH], kch[NCH], vch[NCH];
@@ -133,8 +139,8 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
     srow[i] = RPI * j + lane / CPR;
     kch[i] = (lane % CPR) ^ f_k(srow[i]);
     vch[i] = (lane % CPR) ^ f_v(srow[i]);
-    kptr[i] = p.K + (int64_t)(row0 + srow[i]) * p.ldk + head * D + kch[i] * 8;
-    vptr[i] = p.V + (int64_t)(row0 + srow[i]) * p.ldv + head * D + vch[i] * 8;
+    kptr[i] = kbase + (int64_t)srow[i] * p.ldk + kch[i] * 8;
+    vptr[i] = vbase + (int64_t)srow[i] * p.ldv + vch[i] * 8;
   }
   const int64_t kstep = 64 * p.ldk, vstep = 64 * p.ldv;
   typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -152,9 +158,9 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
     } else {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int64_t grow = row0 + min(k0 + srow[i], len - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.K + grow * p.ldk + head * D + kch[i] * 8), (lptr_t)(k_w + i * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.V + grow * p.ldv + head * D + vch[i] * 8), (lptr_t)(v_w + i * 1024), 16, 0, 0);
+        const int64_t grow = min(k0 + srow[i], len - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(kbase + grow * p.ldk + kch[i] * 8), (lptr_t)(k_w + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vbase + grow * p.ldv + vch[i] * 8), (lptr_t)(v_w + i * 1024), 16, 0, 0);
       }
     }
   };
@@ -442,6 +448,10 @@ extern "C" int icl_attn_fwd_bf16(const icl_attn_args* a, void* stream) {
   p.rel_bias = a->rel_bias;
   p.rel_gate = a->rel_gate;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+  ICL_CHECK_ARG((a->kv_seq_stride == 0) == (a->kv_head_stride == 0) && a->kv_seq_stride >= 0 && a->kv_head_stride >= 0 &&
+                    a->kv_seq_stride % 8 == 0 && a->kv_head_stride % 8 == 0,
+                "icl_attn_fwd_bf16: kv_seq_stride / kv_head_stride must both be 0 or both positive multiples of 8");
+  p.kv_seq_stride = a->kv_seq_stride; p.kv_head_stride = a->kv_head_stride;
   p.n_heads = a->n_heads;
   p.rel_span = a->rel_span;
   const int bq = (a->head_dim == 64 && !a->rel_bias) ? 256 : 128;

@@ -440,6 +440,7 @@ struct RopeFuse {
   unsigned short* kc;
   unsigned short* vc;
   int k_off, v_off, H, max_len;
+  int kv_rows_to_c;   // 0: k / v go to the cache only (the prefill attention reads them there)
 };
 
 __device__ __forceinline__ void rope_rows(const GemmParams& p, const RopeFuse& rf, const char* smem, int pitch, int m0,
@@ -463,7 +464,7 @@ __device__ __forceinline__ void rope_rows(const GemmParams& p, const RopeFuse& r
         const int c = base + u * 512, row = c >> 5, cc = c & 31, m = m0 + row;
         if (m >= p.M) continue;
         const u32x4 v = *(const u32x4*)(smem + row * pitch + cc * 16);
-        *(u32x4*)(C + (int64_t)m * p.ldc + n0 + cc * 8) = v;
+        if (rf.kv_rows_to_c) *(u32x4*)(C + (int64_t)m * p.ldc + n0 + cc * 8) = v;
         if (rf.vc) *(u32x4*)(rf.vc + (crow[u] + (int64_t)(head0 + (cc >> 4)) * rf.max_len) * 128 + (cc & 15) * 8) = v;
       }
     }
@@ -499,9 +500,11 @@ __device__ __forceinline__ void rope_rows(const GemmParams& p, const RopeFuse& r
       if (m >= p.M) continue;
       u32x4 olo, ohi;
       rope_rot8(lo[u], hi[u], c0[u], c1[u], s0[u], s1[u], olo, ohi);
-      unsigned short* dst = C + (int64_t)m * p.ldc + n0 + hh * 128 + j * 8;
-      *(u32x4*)dst = olo;
-      *(u32x4*)(dst + 64) = ohi;
+      if (sect == 0 || rf.kv_rows_to_c) {
+        unsigned short* dst = C + (int64_t)m * p.ldc + n0 + hh * 128 + j * 8;
+        *(u32x4*)dst = olo;
+        *(u32x4*)(dst + 64) = ohi;
+      }
       if (to_cache) {
         unsigned short* cd = rf.kc + (((int64_t)sq[u] * rf.H + head0 + hh) * rf.max_len + ps[u]) * 128 + j * 8;
         *(u32x4*)cd = olo;
@@ -1327,7 +1330,8 @@ extern "C" int icl_gemm_bf16(const icl_gemm_args* a, void* stream) { return gemm
 
 extern "C" int icl_gemm_rope_kv_bf16(const icl_gemm_args* a, int64_t k_off, int64_t v_off, const float* cosT,
                                      const float* sinT, const int32_t* pos, const int32_t* seq_ids, void* kcache,
-                                     void* vcache, int32_t n_heads, int32_t head_dim, int32_t max_len, void* stream) {
+                                     void* vcache, int32_t n_heads, int32_t head_dim, int32_t max_len, int32_t kv_rows_to_c,
+                                     void* stream) {
   ICL_CHECK_ARG(a != nullptr && cosT && sinT && pos, "icl_gemm_rope_kv_bf16: NULL pointer");
   ICL_CHECK_ARG(head_dim == 128, "icl_gemm_rope_kv_bf16: head_dim=%d (the fused epilogue is built for 128)", head_dim);
   ICL_CHECK_ARG(n_heads > 0 && k_off == (int64_t)n_heads * 128 && v_off == 2 * k_off && a->N == 3 * k_off && k_off % 256 == 0,
@@ -1343,7 +1347,9 @@ extern "C" int icl_gemm_rope_kv_bf16(const icl_gemm_args* a, int64_t k_off, int6
     ICL_CHECK_ARG(seq_ids && max_len > 0, "icl_gemm_rope_kv_bf16: cache append needs seq_ids and max_len");
     ICL_CHECK_ARG(((uintptr_t)kcache & 15) == 0 && ((uintptr_t)vcache & 15) == 0, "icl_gemm_rope_kv_bf16: cache misaligned");
   }
+  ICL_CHECK_ARG(kv_rows_to_c || kcache, "icl_gemm_rope_kv_bf16: kv_rows_to_c = 0 needs a cache to hold k / v");
   RopeFuse rf;
+  rf.kv_rows_to_c = kv_rows_to_c;
   rf.cosT = cosT; rf.sinT = sinT; rf.pos = pos; rf.seq_ids = seq_ids;
   rf.kc = (unsigned short*)kcache; rf.vc = (unsigned short*)vcache;
   rf.k_off = (int)k_off; rf.v_off = (int)v_off; rf.H = n_heads; rf.max_len = max_len;

@@ -18,7 +18,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libicl_hip.so"))
 
 ICL_BF16, ICL_F32 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 1, 2, 4, 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
@@ -47,7 +47,8 @@ class AttnArgs(Structure):
         ("cu_seqlens", c_void_p), ("kv_lens", c_void_p), ("rel_bias", c_void_p), ("rel_gate", c_void_p),
         ("ldq", c_int64), ("ldk", c_int64), ("ldv", c_int64), ("ldo", c_int64),
         ("n_seqs", c_int32), ("max_seqlen", c_int32), ("n_heads", c_int32), ("head_dim", c_int32),
-        ("causal", c_int32), ("rel_span", c_int32), ("scale", c_float),
+        ("causal", c_int32), ("rel_span", c_int32), ("scale", c_float), ("reserved", c_int32),
+        ("kv_seq_stride", c_int64), ("kv_head_stride", c_int64),
     ]
 
 
@@ -68,7 +69,7 @@ _SIGNATURES = {
     "icl_rope_kv_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "icl_gemm_rope_kv_bf16": (c_int, [POINTER(GemmArgs), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+                                      c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "icl_pack_decode_weights": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "icl_embed_gather_interleave": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                             c_int32, c_int32, c_void_p]),
@@ -160,7 +161,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, resi
          batch: int = 1, stride_a: int = 0, stride_c: int = 0, stride_r: int = 0, rope=None, N=None) -> torch.Tensor:
     """out = epilogue(a @ w.T).  a: bf16 [M,K] (row stride lda), w: bf16 [N,K], out: bf16|f32 [M,N'].
 
-    ``rope`` = (k_off, v_off, cos, sin, pos, seq_ids, kcache, vcache, n_heads, head_dim, max_len) runs the QKV projection
+    ``rope`` = (k_off, v_off, cos, sin, pos, seq_ids, kcache, vcache, n_heads, head_dim, max_len[, kv_rows_to_c]) runs the QKV projection
     with RoPE + KV-cache append fused into its epilogue (icl_gemm_rope_kv_bf16; see ``rope_fusable``)."""
     _require_gpu(a, w, out, bias, residual, workspace)
     lib = load_library()
@@ -197,13 +198,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, resi
     if split_k > 1 and workspace is not None:
         assert workspace.dtype == torch.float32 and workspace.numel() >= split_k * g.M * N
     if rope is not None:
-        k_off, v_off, cos, sin, pos, seq_ids, kcache, vcache, n_heads, head_dim, max_len = rope
+        k_off, v_off, cos, sin, pos, seq_ids, kcache, vcache, n_heads, head_dim, max_len = rope[:11]
+        kv_rows_to_c = int(rope[11]) if len(rope) > 11 else 1
         _require_gpu(cos, sin, pos, seq_ids, kcache, vcache)
 
         def launch():
             _check(lib.icl_gemm_rope_kv_bf16(ctypes.byref(g), k_off, v_off, cos.data_ptr(), sin.data_ptr(), pos.data_ptr(),
                                              _ptr(seq_ids), _ptr(kcache), _ptr(vcache), n_heads, head_dim, max_len,
-                                             _stream()), "icl_gemm_rope_kv_bf16")
+                                             kv_rows_to_c, _stream()), "icl_gemm_rope_kv_bf16")
     else:
         def launch():
             _check(lib.icl_gemm_bf16(ctypes.byref(g), _stream()), "icl_gemm_bf16")
@@ -237,7 +239,8 @@ def rope_fusable(M: int, n_heads: int, head_dim: int, K: int) -> bool:
 
 
 def attn_fwd(q, k, v, out, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: int, scale: float, *,
-             causal=False, kv_lens=None, rel_bias=None, rel_gate=None, rel_span: int = 0):
+             causal=False, kv_lens=None, rel_bias=None, rel_gate=None, rel_span: int = 0, kv_cache_max_len: int = 0):
+    """``kv_cache_max_len`` > 0: k / v are KV-cache tensors [n_seqs, n_heads, max_len, head_dim] (read in place)."""
     _require_gpu(q, k, v, out, cu_seqlens, kv_lens, rel_bias, rel_gate)
     lib = load_library()
     a = AttnArgs()
@@ -245,6 +248,12 @@ def attn_fwd(q, k, v, out, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: 
     a.cu_seqlens, a.kv_lens = cu_seqlens.data_ptr(), _ptr(kv_lens)
     a.rel_bias, a.rel_gate = _ptr(rel_bias), _ptr(rel_gate)
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.reserved = 0
+    if kv_cache_max_len > 0:
+        a.ldk = a.ldv = head_dim
+        a.kv_seq_stride, a.kv_head_stride = n_heads * kv_cache_max_len * head_dim, kv_cache_max_len * head_dim
+    else:
+        a.kv_seq_stride = a.kv_head_stride = 0
     a.n_seqs = cu_seqlens.numel() - 1
     a.max_seqlen, a.n_heads, a.head_dim = max_seqlen, n_heads, head_dim
     a.causal, a.rel_span, a.scale = int(causal), rel_span, scale

@@ -329,7 +329,7 @@ class LlamaHIP:
 
     # ---- one decoder layer over M packed rows ---------------------------------------------------
     def _layer(self, ws: Workspace, L, h, M: int, tag: str, attn_fn, pos, seq_ids, kc, vc, max_len: int,
-               split: Optional[dict] = None):
+               split: Optional[dict] = None, kv_rows_to_c: bool = True):
         c, w = self.w.cfg, self.w
         hd, I, D, H = c.hidden, c.ffn, c.head_dim, c.n_heads
         xn = ws.get(tag + "xn", (M, w.k_aug), BF16, zero=True)   # augmentation tail stays zero
@@ -352,7 +352,7 @@ class LlamaHIP:
         if split is None and B.rope_fusable(M, H, D, L.wqkv.shape[1]):
             # prefill on the 256x256 tile: RoPE + cache append run in the GEMM's staged epilogue (same bits as the two calls)
             B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, tile=3,
-                   rope=(hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len))
+                   rope=(hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, kv_rows_to_c))
         else:
             B.gemm(xn, L.decode_packed[0] if sk.get("tile") in (5, 6) else L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1),
                    workspace=wsk, tile=sk.get("tile", 0), N=3 * hd, K=w.k_aug)
@@ -383,13 +383,23 @@ class LlamaHIP:
         maxS = max(seq_lens)
         H, D, hd = c.n_heads, c.head_dim, c.hidden
 
+        # With a cache and the fused QKV epilogue, k / v are written ONCE — into the cache — and the attention reads them
+        # there ([seq][head][pos][D]: 256-B rows at a 256-B stride instead of a 3*hidden stride); the k / v columns of the QKV
+        # buffer are never written.  Without a cache (teacher-forced forward) they stay packed next to q.
+        kv_from_cache = cache is not None and B.rope_fusable(M, H, D, self.w.k_aug)
+
         def attn(qkv, att):
             B.attn_fwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], att, cu, maxS, H, D, D ** -0.5, causal=True)
 
         for i, L in enumerate(self.w.layers):
             kc = cache.k[i] if cache is not None else None
             vc = cache.v[i] if cache is not None else None
-            self._layer(ws, L, h, M, "pf_", attn, pos, sid, kc, vc, cache.max_len if cache is not None else 0)
+            fn = attn
+            if kv_from_cache:
+                def fn(qkv, att, kc=kc, vc=vc):
+                    B.attn_fwd(qkv[:, :hd], kc, vc, att, cu, maxS, H, D, D ** -0.5, causal=True, kv_cache_max_len=cache.max_len)
+            self._layer(ws, L, h, M, "pf_", fn, pos, sid, kc, vc, cache.max_len if cache is not None else 0,
+                        kv_rows_to_c=not kv_from_cache)
         return h
 
     def logits(self, ws: Workspace, h_rows: torch.Tensor, name: str = "ll_logits") -> torch.Tensor:

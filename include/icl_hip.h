@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICL_ABI_VERSION 1
+#define ICL_ABI_VERSION 2
 
 /* error codes */
 #define ICL_OK 0
@@ -130,6 +130,13 @@ typedef struct icl_attn_args {
   int32_t n_seqs, max_seqlen, n_heads, head_dim;
   int32_t causal, rel_span;
   float scale;
+  int32_t reserved;                            /* 0 */
+  int64_t kv_seq_stride, kv_head_stride;       /* both 0: K/V rows are packed like Q (row cu_seqlens[s] + j, head h at
+                                                  column h*head_dim, row strides ldk / ldv).  Both > 0: K/V are read from a
+                                                  cache, key j of (sequence s, head h) at K + s*kv_seq_stride +
+                                                  h*kv_head_stride + j*ldk (elements) — the Llama prefill reads back what
+                                                  the fused QKV epilogue appended: [n_seqs][n_heads][max_len][head_dim],
+                                                  ldk = ldv = head_dim                                              */
 } icl_attn_args;
 
 int icl_attn_fwd_bf16(const icl_attn_args* args, void* stream);
@@ -185,13 +192,16 @@ int icl_rope_kv_bf16(void* qkv, int64_t ld, int64_t k_off, int64_t v_off, const 
  * args: batch 1, bf16 output, epilogue 0 or ICL_EPI_BIAS, N = 3*n_heads*128 with q|k|v column
  * blocks at 0 | k_off | v_off, n_heads*128 a multiple of 256; the problem must resolve to the
  * 256x256 tile (icl_gemm_select_tile(...) == 3 and K >= 128) — otherwise ICL_EINVAL, and the
- * caller issues the two calls.  Remaining arguments as icl_rope_kv_bf16.
+ * caller issues the two calls.  Remaining arguments as icl_rope_kv_bf16.  kv_rows_to_c = 0 (needs a cache): the k / v
+ * column blocks of C are NOT written — they exist only in the cache, where icl_attn_fwd_bf16 can read them
+ * (kv_seq_stride / kv_head_stride); q is always written.
  * Replaces q_proj/k_proj/v_proj + apply_rotary_pos_emb + DynamicCache.update of transformers'
  * LlamaAttention, reached from models/custom_salmon.py:630-636 (prefill).
  */
 int icl_gemm_rope_kv_bf16(const icl_gemm_args* args, int64_t k_off, int64_t v_off, const float* cos,
                           const float* sin, const int32_t* pos, const int32_t* seq_ids, void* kcache,
-                          void* vcache, int32_t n_heads, int32_t head_dim, int32_t max_len, void* stream);
+                          void* vcache, int32_t n_heads, int32_t head_dim, int32_t max_len, int32_t kv_rows_to_c,
+                          void* stream);
 
 /* ---- K9: token-embedding gather + speech interleave --------------------------------------
  * out[r][:] = src_idx[r] >= 0 ? table[src_idx[r]][:] : speech[-src_idx[r]-1][:]

@@ -245,6 +245,29 @@ def test_attn_fwd(B, D, H, causal, lens):
     assert _relerr(out, ref) < 1e-2
 
 
+@pytest.mark.parametrize("D,H,causal", [(128, 3, True), (64, 2, False)])
+def test_attn_fwd_reads_kv_from_cache_layout(B, D, H, causal):
+    """K / V addressed as [seq][head][pos][D] cache rows (what the fused QKV epilogue appends) == the packed-row form, bit
+    for bit; cache rows past a sequence's length hold NaN and must never reach the output."""
+    lens = [70, 1, 129, 200]
+    M, max_len = sum(lens), 256
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    q, k, v = (_rand_bf16(M, H * D, seed=71 + i) for i in range(3))
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    ref = torch.empty(M, H * D, dtype=torch.bfloat16, device=DEV)
+    B.attn_fwd(q, k, v, ref, cu_t, max(lens), H, D, D ** -0.5, causal=causal)
+    kc = torch.full((len(lens), H, max_len, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    vc = torch.full_like(kc, float("nan"))
+    for s, n in enumerate(lens):
+        kc[s, :, :n] = k[cu[s]:cu[s + 1]].view(n, H, D).transpose(0, 1)
+        vc[s, :, :n] = v[cu[s]:cu[s + 1]].view(n, H, D).transpose(0, 1)
+    out = torch.empty_like(ref)
+    B.attn_fwd(q, kc, vc, out, cu_t, max(lens), H, D, D ** -0.5, causal=causal, kv_cache_max_len=max_len)
+    assert torch.equal(out, ref)
+
+
 def test_attn_fwd_kv_lens_and_spike(B):
     # key padding + a spiked key that forces the online-softmax rescale late in the sequence
     D, H, lens = 64, 2, [300, 130]
@@ -409,6 +432,14 @@ def test_gemm_rope_kv_fused_is_bit_identical(B, M, with_bias):
     assert torch.equal(out[:M], ref)
     assert torch.equal(out[M:], torch.full((3, 3 * hd), 7.0, dtype=torch.bfloat16, device=DEV))
     assert torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
+    # k / v to the cache only: the q block as before, the k / v column blocks of C untouched
+    out3 = torch.full((M, 3 * hd), 7.0, dtype=torch.bfloat16, device=DEV)
+    kc2, vc2 = torch.zeros_like(kc0), torch.zeros_like(kc0)
+    B.gemm(x, w, out3, bias=bias, tile=3, rope=(hd, 2 * hd, cos, sin, pos, sid, kc2, vc2, H, D, max_len, 0))
+    assert torch.equal(out3[:, :hd], ref[:, :hd]) and bool((out3[:, hd:] == 7.0).all())
+    assert torch.equal(kc2, kc0) and torch.equal(vc2, vc0)
+    with pytest.raises(RuntimeError, match="needs a cache"):
+        B.gemm(x, w, out3, bias=bias, tile=3, rope=(hd, 2 * hd, cos, sin, pos, None, None, None, H, D, max_len, 0))
     # and without a cache (training-style forward): rows only
     out2 = torch.empty(M, 3 * hd, dtype=torch.bfloat16, device=DEV)
     B.gemm(x, w, out2, bias=bias, tile=3, rope=(hd, 2 * hd, cos, sin, pos, None, None, None, H, D, max_len))
