@@ -728,7 +728,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p, Rope
     const int pitch = out_cols * es + 16;                        // bytes per staged row
     const int chunks_per_row = out_cols * es / 16;               // 16-B pieces per row: 16 | 32 | 64
     const int64_t c_col0 = swiglu ? (n0 >> 1) : n0;
-    const bool one_round = ROPE || obf;                          // a bf16 tile fits whole: two barriers instead of four
+    const bool one_round = ROPE || obf;                          // a bf16 tile fits whole: two barriers instead of four (two rounds
+                                                                 // under GELU, to drain stores behind the second half's VALU work: no gain)
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
       if (qa == 0 || !one_round) __syncthreads();                // K-tile reads (qa = 0) / the previous half's row reads are done
@@ -1211,6 +1212,8 @@ int launch_tile(GemmParams& p, int batch, hipStream_t stream) {
 extern "C" int icl_gemm_select_tile(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t split_k) {
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
   if (split_k > 1 || M <= 64 || t128 < 256) return 2;
+  if (N <= 64) return 2;    // a wider tile multiplies padding columns: BEATs grouped pos-conv (N = 48) 376 us on 256x256, 215 on 64x64
+  if (N <= 128) return 1;
   static int ncu = 0;
   if (ncu <= 0) {
     ncu = icl_device_cu_count();
