@@ -279,8 +279,9 @@ def main():
         try:   # HBM-side bytes per launch of this kernel from the committed PMC passes of this same command (profiles/)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             key = {1: "gemm_bf16_kernel<2, 2, 4, 4>", 2: "gemm_bf16_kernel<2, 2, 2, 2>", 3: "gemm256_bf16_kernel"}[dom]
-            if f"(batch {Bm})" in pmc["command"] and not args.tiny:
-                traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+            if f"(batch {Bm}" in pmc["command"] and not args.tiny:
+                rows = [v for k, v in pmc["kernels"].items() if k == key or k.startswith(key + "<")]   # all instantiations
+                traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows))
         except Exception:
             traffic = None
         roof = {"bound": "mfma", "kernel": names.get(dom, str(dom)), "achieved": round(fl / tt / 1e12, 1),
