@@ -20,23 +20,41 @@ BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
 
 class Workspace:
-    """Named device buffers keyed by (name, shape, dtype); reused across calls so the steady-state
-    loop performs no allocation (and decode graphs can capture stable pointers)."""
+    """Named device buffers with a CAPACITY: one flat allocation per (name, dtype) that only ever grows to the largest
+    request seen, handed out as a leading ``[:numel]`` view in the requested shape.  Ragged batches (a new total row count
+    on almost every call) therefore reuse the same storage — resident bytes are bounded by the largest batch, not by
+    the number of distinct shapes — and the steady-state loop performs no allocation.
+
+    ``generation`` counts reallocations: anything that baked raw pointers (captured decode graphs) must be dropped when
+    it moves (``CausalLMRuntimeMixin`` does).  ``zero=True`` buffers carry regions the kernels never write and rely on being
+    zero (conv padding rows, the LoRA augmentation tail): those regions sit at fixed flat offsets for fixed inner
+    dimensions, so the buffer is zero-filled when it is (re)allocated and again whenever the inner dimensions change."""
 
     def __init__(self, device):
         self.device = torch.device(device)
-        self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._bufs: Dict[tuple, list] = {}      # (name, dtype) -> [flat tensor, inner dims of the last zero=True request]
+        self.generation = 0
 
     def get(self, name: str, shape: Sequence[int], dtype, zero: bool = False) -> torch.Tensor:
-        key = (name, tuple(int(s) for s in shape), dtype)
-        t = self._bufs.get(key)
-        if t is None:
-            t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
-            self._bufs[key] = t
-        return t
+        shape = tuple(int(s) for s in shape)
+        n = 1
+        for s in shape:
+            n *= s
+        key = (name, dtype)
+        ent = self._bufs.get(key)
+        if ent is None or ent[0].numel() < n:
+            if ent is not None:
+                ent[0] = None                   # release the old block before asking for the larger one
+                self.generation += 1
+            flat = (torch.zeros if zero else torch.empty)(max(n, 1), dtype=dtype, device=self.device)
+            ent = self._bufs[key] = [flat, shape[1:]]
+        elif zero and ent[1] != shape[1:]:
+            ent[0].zero_()
+            ent[1] = shape[1:]
+        return ent[0][:n].view(shape)
 
     def nbytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in self._bufs.values())
+        return sum(e[0].numel() * e[0].element_size() for e in self._bufs.values())
 
 
 def _i32(x, device) -> torch.Tensor:
@@ -458,10 +476,11 @@ class LlamaHIP:
 
 
 class KVCache:
-    """bf16 K/V cache, per layer [n_seqs][n_heads][max_len][head_dim] (one contiguous stream per (seq, head))."""
+    """bf16 K/V cache, per layer [n_seqs][n_heads][max_len][head_dim] (one contiguous stream per (seq, head)): a view of
+    the workspace's single ``kv_k`` / ``kv_v`` allocations, which grow to the largest (n_seqs x max_len) seen."""
 
-    def __init__(self, cfg, n_seqs: int, max_len: int, device):
+    def __init__(self, cfg, n_seqs: int, max_len: int, ws: Workspace):
         self.n_seqs, self.max_len = n_seqs, max_len
         shape = (cfg.n_layers, n_seqs, cfg.n_heads, max_len, cfg.head_dim)
-        self.k = torch.empty(shape, dtype=BF16, device=device)
-        self.v = torch.empty(shape, dtype=BF16, device=device)
+        self.k = ws.get("kv_k", shape, BF16)
+        self.v = ws.get("kv_v", shape, BF16)

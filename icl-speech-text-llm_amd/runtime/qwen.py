@@ -52,8 +52,7 @@ class QwenAudioRuntime(CausalLMRuntimeMixin):
         self.tower = QwenAudioTowerHIP(enc, _bf(_take(sd, "multi_modal_projector.linear.weight", consume), self.device),
                                        _f32(_take(sd, "multi_modal_projector.linear.bias", consume), self.device), cfg.llm.hidden)
         self.llama = LlamaHIP(pack_llama(sd, cfg.llm, self.device, prefix="language_model.", consume=consume), self.device)
-        self._caches = {}
-        self._graphs, self._graph_warm = {}, set()
+        self._graphs, self._graph_warm, self._graph_gen = {}, set(), 0
 
     # ---- K13 ---------------------------------------------------------------------------------------
     def encode_audio(self, input_features: Optional[torch.Tensor] = None, mel_lens: Optional[Sequence[int]] = None,

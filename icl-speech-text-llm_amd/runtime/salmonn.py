@@ -92,16 +92,22 @@ class CausalLMRuntimeMixin:
     # --------------------------------------------------------------------------------------------
     # K10 + K11: greedy generate
     # --------------------------------------------------------------------------------------------
+    MAX_GRAPHS = 16            # captured decode graphs kept (one per batch shape / cache length / knob set); oldest dropped
+
     def _cache(self, n_seqs: int, max_len: int) -> KVCache:
-        key = (n_seqs, max_len)
-        c = self._caches.get(key)
-        if c is None:
-            if len(self._caches) > 4:     # captured decode graphs hold raw pointers into these caches: drop them together
-                self._caches.clear()
-                self._graphs.clear()
-                self._graph_warm.clear()
-            c = self._caches[key] = KVCache(self.lm_cfg, n_seqs, max_len, self.device)
-        return c
+        """K/V views over the workspace's one K and one V allocation (they grow to the largest n_seqs x max_len seen; a
+        move bumps ``ws.generation``, which retires every captured graph)."""
+        return KVCache(self.lm_cfg, n_seqs, max_len, self.ws)
+
+    def _graph_lookup(self, gkey):
+        """(captured graph | None, warm?) for this key, after retiring everything captured or warmed under an older
+        workspace generation: a graph bakes raw pointers into workspace buffers and must not outlive a reallocation."""
+        gen = self.ws.generation
+        if self._graph_gen != gen:
+            self._graphs.clear()
+            self._graph_warm.clear()
+            self._graph_gen = gen
+        return self._graphs.get(gkey), gkey in self._graph_warm
 
     def generate(self, prompts, speech: Optional[torch.Tensor], max_new_tokens: int = 10, eos_id: Optional[int] = None,
                  pad_id: Optional[int] = None, suppress_eos: bool = False, want_first_logits: bool = False,
@@ -190,19 +196,27 @@ class CausalLMRuntimeMixin:
             # sizes every workspace buffer, it is captured ONCE per (batch, cache length, steps, eos, pad) into a HIP
             # graph and replayed — all pointers are workspace-stable and nothing inside synchronises or allocates.
             gkey = (Bn, max_len, steps, eos, pad, knobs)
-            graph = self._graphs.get(gkey) if self.use_graphs else None
+            graph, warm = self._graph_lookup(gkey) if self.use_graphs else (None, False)
             if graph is not None:
                 graph.replay()
-            elif self.use_graphs and gkey in self._graph_warm:
+            elif warm:
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
-                    decode_loop()
+                prof, B.GEMM_PROFILE = B.GEMM_PROFILE, None      # no timing events inside a stream capture
+                try:
+                    with torch.cuda.graph(g):
+                        decode_loop()
+                finally:
+                    B.GEMM_PROFILE = prof
+                while len(self._graphs) >= self.MAX_GRAPHS:
+                    self._graphs.pop(next(iter(self._graphs)))
                 self._graphs[gkey] = g
                 g.replay()
             else:
                 decode_loop()
-                self._graph_warm.add(gkey)
+                if self.use_graphs:
+                    self._graph_lookup(gkey)                     # the eager pass may have grown buffers: re-sync first
+                    self._graph_warm.add(gkey)
         if marks is not None:
             marks["decode_end"].record()
         out = toks.cpu().to(torch.int64)                                                 # the only D2H of the call
@@ -237,8 +251,7 @@ class SalmonnRuntime(CausalLMRuntimeMixin):
                                             cfg.llama.hidden)
         if "llama" in parts:
             self.llama = LlamaHIP(pack_llama(sd, cfg.llama, self.device, consume=consume), self.device)
-        self._caches: Dict[tuple, KVCache] = {}
-        self._graphs, self._graph_warm = {}, set()
+        self._graphs, self._graph_warm, self._graph_gen = {}, set(), 0
 
     # --------------------------------------------------------------------------------------------
     # K1-K8: SALMONN.encode_speech

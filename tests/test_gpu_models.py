@@ -312,3 +312,39 @@ def test_generate_sampled_and_penalised_greedy(env):
                 lg = ob.logits(ob.forward_hidden(ob.embed(torch.tensor([tok]))[:, None], torch.full((1, 1), T + step), cache))[0, 0]
         ids, _ = ob.generate_sampled(emb, 3, -1, cfg.llama.pad_id, None, do_sample=False, repetition_penalty=1.5)
         assert ids.shape == (1, 3)
+
+
+def test_workspace_stays_bounded_over_ragged_batches(env):
+    """a dataset run sees a new total row count on almost every batch.  60 ragged batches (distinct packed
+    row totals, batch sizes 1..6, audio 1..4 s) after one largest-shape call must not grow the workspace by a byte, must not
+    move a buffer (generation constant), and must leave results bit-identical to the first time a batch was seen."""
+    cfg, sd, rt = env
+    rng = np.random.default_rng(77)
+    big = _prompts(cfg, [64] * 6, seed=900)
+    wav_big = _wavs([64000] * 6)
+    rt.encode_speech(wav_big, [64000] * 6)
+    rt.generate(big, None, max_new_tokens=6, suppress_eos=True)
+    rt.forward_logits(big, None)
+    probe = _prompts(cfg, [33, 12, 50], seed=901)
+    want = rt.generate(probe, None, max_new_tokens=6, suppress_eos=True, want_first_logits=True)
+    want_tok, want_first = want.tokens.clone(), want.first_logits.clone()
+    probe_wav = _wavs([30000, 47000])
+    want_emb = rt.encode_speech(probe_wav, [30000, 47000]).clone()
+    bytes0, gen0 = rt.ws.nbytes(), rt.ws.generation
+    totals = set()
+    for it in range(60):
+        b = int(rng.integers(1, 7))
+        lens = rng.integers(5, 65, b).tolist()
+        totals.add(sum(lens))
+        rt.generate(_prompts(cfg, lens, seed=1000 + it), None, max_new_tokens=int(rng.integers(2, 7)), suppress_eos=True)
+        wl = rng.integers(16000, 64001, int(rng.integers(1, 7))).tolist()
+        rt.encode_speech(_wavs(wl), wl)
+        if it % 10 == 0:
+            rt.forward_logits(_prompts(cfg, lens, seed=2000 + it), None)
+    assert len(totals) >= 40
+    assert rt.ws.nbytes() == bytes0, f"workspace grew from {bytes0} to {rt.ws.nbytes()} bytes over ragged batches"
+    assert rt.ws.generation == gen0
+    assert len(rt._graphs) <= rt.MAX_GRAPHS
+    again = rt.generate(probe, None, max_new_tokens=6, suppress_eos=True, want_first_logits=True)
+    assert torch.equal(again.tokens, want_tok) and torch.equal(again.first_logits, want_first)
+    assert torch.equal(rt.encode_speech(probe_wav, [30000, 47000]), want_emb)

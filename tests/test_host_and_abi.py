@@ -263,3 +263,42 @@ def test_performance_tracker_matches_reference(monkeypatch):
         tr.log_summary()
         monkeypatch.undo()
         assert summary == want["summary"] and lines == want["lines"], interval
+
+
+def test_workspace_capacity_is_bounded_and_tracks_generation():
+    """buffers are keyed by name with a capacity — 200 distinct ragged row counts keep ONE allocation per
+    name (bytes bounded by the largest request), growth bumps `generation` (captured graphs must be retired), and zero=True
+    buffers are re-zeroed when their inner dimensions change (their never-written regions sit at fixed flat offsets only
+    for fixed inner dims)."""
+    import numpy as np
+    import torch
+    from icl_speech_text_llm_amd.runtime.engines import Workspace, KVCache
+    ws = Workspace("cpu")
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(1, 5000, 200).tolist()
+    for m in sizes:
+        t = ws.get("pf_qkv", (m, 96), torch.bfloat16)
+        assert t.shape == (m, 96) and t.is_contiguous()
+        ws.get("pf_h", (m, 32), torch.float32)
+    assert ws.nbytes() == max(sizes) * (96 * 2 + 32 * 4)
+    gen = ws.generation
+    assert 0 < gen <= 2 * 12          # ~ln(200) record highs per name, not one per shape
+    a = ws.get("pf_qkv", (17, 96), torch.bfloat16)
+    b = ws.get("pf_qkv", (4000, 96), torch.bfloat16)
+    assert a.data_ptr() == b.data_ptr() and ws.generation == gen          # within capacity: same storage, no bump
+    ws.get("pf_qkv", (6000, 96), torch.bfloat16)
+    assert ws.generation == gen + 1
+    # zero=True: tail columns stay zero across row counts; a change of inner dims re-zeroes
+    z = ws.get("xn", (8, 40), torch.float32, zero=True)
+    z[:, :32] = 1.0
+    z2 = ws.get("xn", (5, 40), torch.float32, zero=True)
+    assert float(z2[:, 32:].abs().sum()) == 0.0 and float(z2[:, :32].sum()) == 5 * 32
+    z3 = ws.get("xn", (4, 50), torch.float32, zero=True)
+    assert float(z3.abs().sum()) == 0.0
+
+    class _C:
+        n_layers, n_heads, head_dim = 2, 4, 8
+    kv1 = KVCache(_C, 3, 64, ws)
+    p = kv1.k.data_ptr()
+    kv2 = KVCache(_C, 2, 64, ws)
+    assert kv2.k.data_ptr() == p and kv2.k.shape == (2, 2, 4, 64, 8)     # one K allocation, re-viewed per batch shape
