@@ -36,6 +36,8 @@ from ..utils.data_utils import load_dataset
 from ..models.model_factory import ModelFactory, load_finetuned_checkpoint
 from ..utils.evaluation_utils import clean_prediction, evaluate_predictions
 from ..utils.performance_utils import PerformanceTracker
+from ..runtime.binding import IclError
+from ..runtime.dp import collective_device, gather_json_records, gather_results, shard_indices
 
 logger = logging.getLogger(__name__)
 
@@ -86,6 +88,47 @@ def parse_args(argv=None):
 def _dist_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     return int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _tokenizer_of(model):
+    tok = getattr(model, "llama_tokenizer", None)
+    return tok if tok is not None else getattr(getattr(model, "input_processor", None), "tokenizer", None)
+
+
+def _pad_token_id(model) -> int:
+    tok = _tokenizer_of(model)
+    pad = getattr(tok, "pad_token_id", None)
+    return int(pad) if pad is not None else 0
+
+
+def _label_token_ids(model, dataset_types):
+    """First token id of every valid label of the run's tasks: the label-restricted slice of the first-step logits that the
+    data-parallel gather carries.  Empty when no task has a closed label set."""
+    from ..data.task_configs import get_dataset_config
+    tok = _tokenizer_of(model)
+    names: List[str] = []
+    for dt in dataset_types:
+        cfg = get_dataset_config(dt)
+        for lab in (getattr(cfg, "valid_labels", None) or []):
+            if lab not in names:
+                names.append(lab)
+    ids = []
+    for lab in names:
+        enc = tok(lab, add_special_tokens=False)["input_ids"]
+        enc = enc.reshape(-1).tolist() if hasattr(enc, "reshape") else list(enc)
+        ids.append(int(enc[0]) if enc else 0)
+    return names, ids
+
+
+def _generated_lengths(tokens: torch.Tensor, eos_id) -> torch.Tensor:
+    """Tokens each row produced before its pad fill: up to and including the first EOS, else the full width."""
+    n, w = tokens.shape
+    out = torch.full((n,), w, dtype=torch.int32)
+    if eos_id is not None and w:
+        is_eos = tokens == int(eos_id)
+        has = is_eos.any(1)
+        out[has] = (is_eos.float().argmax(1)[has] + 1).to(torch.int32)
+    return out
 
 
 def run_inference(args) -> Dict[str, Any]:
@@ -147,45 +190,84 @@ def run_inference(args) -> Dict[str, Any]:
                                           input_mode=args.input_mode, fewshot_mode=args.fewshot_mode, seed=1234,
                                           interleave=args.interleave)
         total = len(dataset) if args.max_samples is None else min(len(dataset), args.max_samples)
-        indices = list(range(rank, total, world))     # shard by rank, no padding duplicates
+        indices = shard_indices(total, rank, world)   # i ≡ rank (mod world), no padding duplicates
         loader = DataLoader(Subset(dataset, indices), batch_size=args.batch_size, shuffle=False,
                             num_workers=args.num_workers, pin_memory=args.pin_memory and torch.cuda.is_available(),
                             collate_fn=processor.collate_batch)
         model.eval()
-        results: List[Dict[str, Any]] = []
+        label_names, label_ids = _label_token_ids(model, dataset_types)
+        pad_id = _pad_token_id(model)
+        eos_id = getattr(_tokenizer_of(model), "eos_token_id", None)
+        rows: Dict[int, Dict[str, Any]] = {}         # dataset index -> record (strings) of THIS rank
+        ids_l, len_l, logit_l, idx_l = [], [], [], []
+        failed_batches = 0
         with torch.no_grad():
             for batch_idx, batch in enumerate(loader):
+                n_b = len(batch["prompt"])
+                b_idx = indices[batch_idx * args.batch_size: batch_idx * args.batch_size + n_b]
                 try:
                     batch = {k: (v.to(args.device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
                     batch["max_new_tokens"] = args.max_new_tokens
                     t0 = time.time()
-                    outputs = model.generate_output(batch)
+                    res = model.generate_ids(batch, want_first_logits=True)
+                    outputs = model.decode_ids(res.tokens)
                     dt = time.time() - t0
+                    toks = torch.full((n_b, args.max_new_tokens), pad_id, dtype=torch.int32)
+                    toks[:, :res.tokens.shape[1]] = res.tokens.to(torch.int32)
+                    ids_l.append(toks)
+                    len_l.append(_generated_lengths(res.tokens, eos_id))
+                    logit_l.append(res.first_logits[:, label_ids].to(torch.bfloat16).cpu())
+                    idx_l.extend(b_idx)
                     for i, (out, true_label) in enumerate(zip(outputs, batch["completion"])):
                         dt_i = batch["dataset_type"][i]
-                        results.append({"text": batch["text"][i], "true_label": true_label,
-                                        "predicted_label (cleaned)": clean_prediction(out, dt_i),
-                                        "predicted_label": out.strip(), "dataset_type": DatasetType(dt_i).value})
+                        rows[b_idx[i]] = {"text": batch["text"][i], "true_label": true_label,
+                                          "predicted_label (cleaned)": clean_prediction(out, dt_i),
+                                          "predicted_label": out.strip(), "dataset_type": DatasetType(dt_i).value}
                     tracker.update(dt, len(batch["input_ids"]))
+                except (torch.cuda.OutOfMemoryError, IclError):
+                    raise        # device-side failures are not "a bad sample": stop with a non-zero exit code
                 except Exception as e:   # a failed batch is logged and skipped, as in the reference (:370-373)
-                    logger.error("Error processing batch %d: %s", batch_idx, e)
+                    failed_batches += 1
+                    logger.error("Error processing batch %d (dataset indices %s): %s", batch_idx, b_idx, e)
                     logger.debug(traceback.format_exc())
                     continue
         perf = tracker.get_summary()
+        perf["failed_batches"] = failed_batches
         if world > 1:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, results)
-            merged: List[Dict[str, Any]] = []
-            for i in range(max(len(g) for g in gathered)):     # restore the unsharded dataset order
-                for g in gathered:
-                    if i < len(g):
-                        merged.append(g[i])
-            results = merged
-            counts = torch.tensor([perf["total_examples"]], dtype=torch.float64,
-                                  device=args.device if torch.cuda.is_available() else "cpu")
+            # ONE fixed-shape all-gather of (index, gen_ids, gen_len, first-step label logits) + one of the UTF-8 string side;
+            # rank 0 re-orders by DATASET INDEX, so a batch dropped on one rank shows up as missing indices, never as a shift.
+            per_rank = -(-total // world)
+            cat = lambda xs, shape, dt: torch.cat(xs) if xs else torch.zeros(shape, dtype=dt)     # noqa: E731
+            got = gather_results(dist, args.device, torch.tensor(idx_l, dtype=torch.int64),
+                                 cat(ids_l, (0, args.max_new_tokens), torch.int32), cat(len_l, (0,), torch.int32),
+                                 cat(logit_l, (0, len(label_ids)), torch.bfloat16), per_rank)
+            meta = gather_json_records(dist, args.device, [{k: rows[i][k] for k in ("text", "true_label", "dataset_type")}
+                                                           for i in idx_l], idx_l, per_rank)
+            if rank == 0:
+                texts = model.decode_ids(got["gen_ids"].cpu().to(torch.int64))
+                rows = {}
+                for r, i in enumerate(got["index"].tolist()):
+                    m = meta[i]
+                    rows[i] = {"text": m["text"], "true_label": m["true_label"],
+                               "predicted_label (cleaned)": clean_prediction(texts[r], DatasetType(m["dataset_type"])),
+                               "predicted_label": texts[r].strip(), "dataset_type": m["dataset_type"]}
+                    if label_names:
+                        rows[i]["first_step_label_logits"] = dict(zip(label_names, got["first_logits"][r].float().tolist()))
+            counts = torch.tensor([perf["total_examples"], failed_batches], dtype=torch.float64,
+                                  device=collective_device(dist, args.device))
             dist.all_reduce(counts)
-            perf["total_examples_all_ranks"] = int(counts.item())
+            perf["total_examples_all_ranks"], perf["failed_batches"] = int(counts[0].item()), int(counts[1].item())
+        elif label_names:
+            ll = torch.cat(logit_l).float() if logit_l else torch.zeros(0, len(label_ids))
+            for r, i in enumerate(idx_l):
+                rows[i]["first_step_label_logits"] = dict(zip(label_names, ll[r].tolist()))
+        results = [rows[i] for i in sorted(rows)]
         if rank == 0:
+            missing = sorted(set(range(total)) - set(rows))
+            perf["missing_indices"] = missing
+            if missing:
+                logger.error("%d of %d dataset indices have no result (failed batches): %s%s", len(missing), total,
+                             missing[:20], " ..." if len(missing) > 20 else "")
             save_final_results(results, args, results_dir)
             tracker.log_summary()
         return {"results": results, "performance": perf}

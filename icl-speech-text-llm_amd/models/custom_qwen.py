@@ -255,7 +255,8 @@ class CustomQwen(BaseModel):
         self.batch_counter += 1
         return {"loss": loss, "logits": logits, "labels": labels.to(logits.device)}
 
-    def generate_output(self, batch: Dict[str, Any]) -> List[str]:
+    def generate_ids(self, batch: Dict[str, Any], want_first_logits: bool = False):
+        """Batch dict -> ``GenerateResult`` (new token ids, first-step logits on request); see CustomSALMONN.generate_ids."""
         rows, segs, speech, _, _ = self._rows_and_audio(batch)
         # The reference calls generate(max_new_tokens=10) and inherits every other knob from the checkpoint's
         # generation_config.json (custom_qwen.py:227-233), which is not reachable here: greedy by default; ``generation_config``
@@ -266,9 +267,16 @@ class CustomQwen(BaseModel):
                                     eos_id=self.cfg.llm.eos_id, pad_id=self.cfg.llm.pad_id,
                                     do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),
                                     top_p=float(g.get("top_p", 1.0)), top_k=int(g.get("top_k", 50)),
-                                    repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"))
+                                    repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"),
+                                    want_first_logits=want_first_logits)
         self.batch_counter += 1
-        return self.input_processor.batch_decode(res.tokens, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+        return res
+
+    def decode_ids(self, tokens) -> List[str]:
+        return self.input_processor.batch_decode(tokens, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+
+    def generate_output(self, batch: Dict[str, Any]) -> List[str]:
+        return self.decode_ids(self.generate_ids(batch).tokens)
 
     @classmethod
     def from_config(cls, config):

@@ -467,8 +467,10 @@ class CustomSALMONN(BaseModel):
         self.batch_counter += 1
         return {"loss": loss, "logits": logits.view(B, S, -1).clone(), "labels": labels.to(logits.device)}
 
-    def generate_output(self, samples: Dict[str, Any]) -> List[str]:
-        t0 = time.time()
+    def generate_ids(self, samples: Dict[str, Any], want_first_logits: bool = False):
+        """The arithmetic half of ``generate_output``: batch dict -> ``GenerateResult`` (new token ids int64 [B, width] with HF's
+        EOS / pad / width rules, and the first-step logits f32 [B, V] on request).  The data-parallel CLI gathers these as
+        fixed-shape tensors and decodes on rank 0."""
         if samples.get("num_beams", 1) != 1:
             raise NotImplementedError("the MI355X path implements greedy search and sampling, not beam search (num_beams=1)")
         speech_embeds, _, example_embeds, _ = self.get_speech_embeddings(samples)
@@ -482,9 +484,16 @@ class CustomSALMONN(BaseModel):
                                     temperature=float(samples.get("temperature", 0.8)), top_p=float(samples.get("top_p", 0.9)),
                                     top_k=int(samples.get("top_k", 50)),
                                     repetition_penalty=float(samples.get("repetition_penalty", 1.0)),
-                                    generator=samples.get("generator"))
-        preds = self.llama_tokenizer.batch_decode(res.tokens, skip_special_tokens=True)
+                                    generator=samples.get("generator"), want_first_logits=want_first_logits)
         self.batch_counter += 1
+        return res
+
+    def decode_ids(self, tokens) -> List[str]:
+        return self.llama_tokenizer.batch_decode(tokens, skip_special_tokens=True)
+
+    def generate_output(self, samples: Dict[str, Any]) -> List[str]:
+        t0 = time.time()
+        preds = self.decode_ids(self.generate_ids(samples).tokens)
         logger.debug("Generation took %.3f s", time.time() - t0)
         return preds
 

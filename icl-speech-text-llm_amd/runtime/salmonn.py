@@ -30,6 +30,7 @@ def speech_segment(first_row: int, n_rows: int) -> Tuple[str, int, int]:
 class GenerateResult:
     tokens: torch.Tensor          # int64 [B, width] on CPU — what HF generate() returns with inputs_embeds
     first_logits: Optional[torch.Tensor] = None  # f32 [B, V] (device) logits of the first generated position
+    step_logits: Optional[torch.Tensor] = None   # f32 [max_new_tokens, B, V] (device): the logits every token was chosen from
 
 
 class CausalLMRuntimeMixin:
@@ -113,7 +114,7 @@ class CausalLMRuntimeMixin:
                  pad_id: Optional[int] = None, suppress_eos: bool = False, want_first_logits: bool = False,
                  cache_len_multiple: int = 64, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
                  top_k: int = 50, repetition_penalty: float = 1.0, generator: Optional[torch.Generator] = None,
-                 sample_debug=None) -> GenerateResult:
+                 sample_debug=None, want_step_logits: bool = False) -> GenerateResult:
         """Greedy search with HF ``generate(inputs_embeds=…)`` semantics (models/custom_salmon.py:704-720): returns only
         the new tokens; a row that has emitted EOS is filled with pad; the width is that of the longest row
         (``min_length`` is a no-op with inputs_embeds).  All steps are enqueued without a host sync; the
@@ -149,6 +150,9 @@ class CausalLMRuntimeMixin:
         B.gather_rows(h, _i32(cu_last, dev), last)
         logits = self.llama.logits(ws, last, name="gen_logits")
         first = logits.clone() if want_first_logits else None
+        trace = ws.get("gen_logits_trace", (max_new_tokens, Bn, c.vocab), F32) if want_step_logits else None
+        if trace is not None:
+            trace[0].copy_(logits)
         if marks is not None:
             marks["prefill_end"].record()
         finished = ws.get("gen_finished", (Bn,), I32)
@@ -190,12 +194,14 @@ class CausalLMRuntimeMixin:
             def decode_loop():
                 for t in range(steps):
                     lg = self.llama.decode_step(ws, cache, nxt, pos_all[t], len_all[t], sid)
+                    if trace is not None:
+                        trace[t + 1].copy_(lg)
                     tail(lg, t + 1)
 
             # The decode loop is launch-bound at small batch (~17 kernels x layers x steps): after one eager pass that
             # sizes every workspace buffer, it is captured ONCE per (batch, cache length, steps, eos, pad) into a HIP
             # graph and replayed — all pointers are workspace-stable and nothing inside synchronises or allocates.
-            gkey = (Bn, max_len, steps, eos, pad, knobs)
+            gkey = (Bn, max_len, steps, eos, pad, knobs, trace is not None)
             graph, warm = self._graph_lookup(gkey) if self.use_graphs else (None, False)
             if graph is not None:
                 graph.replay()
@@ -225,7 +231,8 @@ class CausalLMRuntimeMixin:
             is_eos = out == eos
             first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((Bn,), max_new_tokens))
             width = int(first_eos.max())
-        return GenerateResult(tokens=out[:, :width].contiguous(), first_logits=first)
+        return GenerateResult(tokens=out[:, :width].contiguous(), first_logits=first,
+                              step_logits=trace.clone() if trace is not None else None)
 
 
 class SalmonnRuntime(CausalLMRuntimeMixin):

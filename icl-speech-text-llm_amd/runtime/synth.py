@@ -126,14 +126,22 @@ def qformer_state(cfg: QFormerCfg, llm_hidden: int, g: _Gen, whisper_d: int, bea
     return sd
 
 
-def llama_state(cfg: LlamaCfg, g: _Gen, prefix: str = "llama_model.") -> SD:
+def llama_state(cfg: LlamaCfg, g: _Gen, prefix: str = "llama_model.", margin: bool = False) -> SD:
+    """``margin=True``: a decoder whose greedy decisions are DECISIVE, for token-exactness checks at full size.  Under the
+    frozen N(0, 0.02^2) weights every layer adds ~2 rms of pseudo-random signal to a 0.02-rms embedding, so the final logits
+    are near-degenerate Gaussians whose top-1 margin is a lottery (0.004 on the bench's first utterance) — no statement about
+    arg-max exactness is possible there.  Here the embedding has unit rms, the two residual writers (o_proj, down_proj) are
+    scaled by 0.05 so the residual stream stays aligned with the last token's embedding (cos ~0.9 after 32 layers), and
+    ``lm_head[perm[t]] = 0.01 * embed[t]`` for a seeded permutation: the next token is perm[last token] with a margin of tens of
+    logits while every kernel of the path (all GEMM tiles, RoPE, cache append, attention, norms, arg-max) still runs at size."""
     h, sd = cfg.hidden, {}
     p = prefix + "model."
-    sd[p + "embed_tokens.weight"] = g.normal(cfg.vocab, h)
+    sd[p + "embed_tokens.weight"] = g.normal(cfg.vocab, h, std=1.0 if margin else 0.02)
+    res_std = 0.001 if margin else 0.02
     for i in range(cfg.n_layers):
         lp = f"{p}layers.{i}."
         for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            sd[lp + f"self_attn.{n}.weight"] = g.normal(h, h)
+            sd[lp + f"self_attn.{n}.weight"] = g.normal(h, h, std=res_std if n == "o_proj" else 0.02)
         if cfg.qkv_bias:
             for n in ("q_proj", "k_proj", "v_proj"):
                 sd[lp + f"self_attn.{n}.bias"] = g.bias(h) if g.jitter else 0.02 * torch.randn(h, generator=g.g, device=g.device)
@@ -143,16 +151,35 @@ def llama_state(cfg: LlamaCfg, g: _Gen, prefix: str = "llama_model.") -> SD:
                 sd[lp + f"self_attn.{n}.lora_B.weight"] = g.normal(h, cfg.lora_rank, std=0.01)
         sd[lp + "mlp.gate_proj.weight"] = g.normal(cfg.ffn, h)
         sd[lp + "mlp.up_proj.weight"] = g.normal(cfg.ffn, h)
-        sd[lp + "mlp.down_proj.weight"] = g.normal(h, cfg.ffn)
+        sd[lp + "mlp.down_proj.weight"] = g.normal(h, cfg.ffn, std=res_std)
         sd[lp + "input_layernorm.weight"] = g.gain(h)
         sd[lp + "post_attention_layernorm.weight"] = g.gain(h)
     sd[p + "norm.weight"] = g.gain(h)
-    sd[prefix + "lm_head.weight"] = g.normal(cfg.vocab, h)
+    if margin:
+        perm = torch.randperm(cfg.vocab, generator=g.g, device=g.device)
+        head = torch.empty_like(sd[p + "embed_tokens.weight"])
+        head[perm] = (sd[p + "embed_tokens.weight"].float() * 0.01).to(head.dtype)
+        sd[prefix + "lm_head.weight"] = head
+    else:
+        sd[prefix + "lm_head.weight"] = g.normal(cfg.vocab, h)
     return sd
 
 
+def margin_successor(sd: SD, prefix: str = "llama_model.") -> torch.Tensor:
+    """perm with lm_head[perm[t]] = 0.01 * embed[t] recovered from a ``margin=True`` state dict (int64 [vocab], on CPU):
+    the token the margin decoder is built to emit after token t."""
+    e = sd[prefix + "model.embed_tokens.weight"].float()
+    w = sd[prefix + "lm_head.weight"].float()
+    probe = torch.randn(e.shape[1], 8, generator=torch.Generator(device=e.device).manual_seed(7), device=e.device)
+    key_e, key_w = (e @ probe) * 0.01, w @ probe                        # 8-dim fingerprints; rows are i.i.d. Gaussian
+    order_e, order_w = torch.argsort(key_e[:, 0]), torch.argsort(key_w[:, 0])
+    perm = torch.empty(e.shape[0], dtype=torch.int64, device=e.device)
+    perm[order_e] = order_w
+    return perm.cpu()
+
+
 def salmonn_state(cfg: SalmonnCfg, seed: int = 0, device="cpu", dtype=torch.float32, jitter: bool = False,
-                  parts=("whisper", "beats", "qformer", "llama")) -> SD:
+                  parts=("whisper", "beats", "qformer", "llama"), margin: bool = False) -> SD:
     """Full synthetic SALMONN checkpoint.  ``dtype`` applies to matrices; gains/biases stay f32."""
     g = _Gen(seed, device, dtype, jitter)
     sd: SD = {}
@@ -164,7 +191,7 @@ def salmonn_state(cfg: SalmonnCfg, seed: int = 0, device="cpu", dtype=torch.floa
         sd.update(qformer_state(cfg.qformer, cfg.llama.hidden, g, cfg.whisper.d_model,
                                 cfg.beats.d_model if cfg.beats is not None else 0))
     if "llama" in parts:
-        sd.update(llama_state(cfg.llama, g))
+        sd.update(llama_state(cfg.llama, g, margin=margin))
     return sd
 
 

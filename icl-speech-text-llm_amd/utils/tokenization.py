@@ -95,6 +95,59 @@ class ByteTokenizer:
         return [self.decode(row, skip_special_tokens=skip_special_tokens) for row in batch]
 
 
+class SubwordStandInTokenizer(ByteTokenizer):
+    """Offline stand-in with the TOKEN COUNT of a sentencepiece Llama tokenizer (~3.9 characters per token on the
+    reference's English prompts) rather than one token per byte: text is cut into space-prefixed word pieces
+    of at most ``piece`` characters (5: 286 / 502 / 330 tokens on the VoxCeleb / HVB / VoxPopuli 5-shot prompts against the survey's 288 / 512 / 320), and each distinct piece gets the next free id (259 .. vocab-2) the first time it is
+    seen, so ``decode`` inverts ``encode`` within one process.  It is NOT a real vocabulary — it exists so that benchmark
+    prompts through the plugin have the prompt length the frozen workload definition assumes (376 positions for C2) when no
+    tokenizer files are reachable; select it with ``llama_path="stand-in:subword"``."""
+
+    def __init__(self, vocab_size: int = 32001, piece: int = 5):
+        super().__init__(vocab_size)
+        self.piece = piece
+        self._ids, self._pieces = {}, {}
+
+    def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
+        out: List[int] = [self.bos_token_id] if add_special_tokens else []
+        i, n = 0, len(text)
+        while i < n:
+            j = i + 1
+            while j < n and j - i < self.piece and text[j] not in " \n":       # a piece never crosses a word boundary
+                j += 1
+            p = text[i:j]
+            t = self._ids.get(p)
+            if t is None:
+                t = 259 + len(self._ids)
+                if t >= self._vocab - 1:                  # vocabulary exhausted: fall back to bytes for this piece
+                    out.extend(b + 3 for b in p.encode("utf-8"))
+                    i = j
+                    continue
+                self._ids[p], self._pieces[t] = t, p
+            out.append(t)
+            i = j
+        return out
+
+    def decode(self, ids, skip_special_tokens: bool = False, **_) -> str:
+        if isinstance(ids, torch.Tensor):
+            ids = ids.tolist()
+        parts, buf = [], bytearray()
+        for t in ids:
+            t = int(t)
+            if 3 <= t < 259:
+                buf.append(t - 3)
+                continue
+            if buf:
+                parts.append(buf.decode("utf-8", errors="replace")); buf = bytearray()
+            if t in self._pieces:
+                parts.append(self._pieces[t])
+            elif not skip_special_tokens and t < 3:
+                parts.append(("<unk>", "<s>", "</s>")[t])
+        if buf:
+            parts.append(buf.decode("utf-8", errors="replace"))
+        return "".join(parts)
+
+
 def load_llama_tokenizer(llama_path: str, vocab_size: int = 32001):
     if llama_path and os.path.isdir(llama_path):
         from transformers import AutoTokenizer
@@ -102,5 +155,7 @@ def load_llama_tokenizer(llama_path: str, vocab_size: int = 32001):
         tok.add_special_tokens({"pad_token": "[PAD]"})
         tok.padding_side = "right"
         return tok
+    if llama_path == "stand-in:subword":
+        return SubwordStandInTokenizer(vocab_size)
     logger.warning("llama_path %r is not a local directory: using the byte-level fallback tokenizer", llama_path)
     return ByteTokenizer(vocab_size)

@@ -42,6 +42,17 @@ def bf16_round(t: Tensor) -> Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def bf16_round_activations(sd: "SD") -> Callable:
+    """``bf16_round`` for ACTIVATIONS only: tensors that are entries of ``sd`` pass through untouched.  Valid when the weights
+    are already bf16-representable (checkpoints generated or stored in bf16) — the rounding of a weight is then the identity
+    and skipping it saves a full pass over the parameters per call (7B: ~10 s of host time per decode step otherwise)."""
+    ptrs = {v.data_ptr() for v in sd.values() if v.dtype == torch.float32}
+
+    def rnd(t: Tensor) -> Tensor:
+        return t if t.data_ptr() in ptrs else bf16_round(t)
+    return rnd
+
+
 def _id(t: Tensor) -> Tensor:
     return t
 
@@ -406,6 +417,21 @@ class LlamaOracle:
             lg = self.logits(self.forward_hidden(e, p, cache))[:, 0]
         ids = torch.stack(out, dim=1)
         return (ids, first) if return_first_logits else ids
+
+    def teacher_forced_logits(self, inputs_embeds: Tensor, tokens: Tensor) -> Tensor:
+        """Logits the greedy loop of ``generate_greedy`` would see if its choices were ``tokens`` [B, n]: prefill, then feed
+        tokens[:, t] at position T + t.  Returns [B, n, V]: row t is the distribution token t is drawn from.  Used to check
+        another implementation's greedy ids decision by decision (each must be this oracle's arg-max up to the logit error),
+        without the two paths diverging after the first numerical coin flip."""
+        B, T, _ = inputs_embeds.shape
+        n = tokens.shape[1]
+        cache: list = []
+        h = self.forward_hidden(inputs_embeds.float(), torch.arange(T)[None].expand(B, T), cache)
+        out = [self.logits(h[:, -1:])[:, 0]]
+        for step in range(n - 1):
+            e = self.embed(tokens[:, step])[:, None]
+            out.append(self.logits(self.forward_hidden(e, torch.full((B, 1), T + step), cache))[:, 0])
+        return torch.stack(out, dim=1)
 
     def generate_sampled(self, inputs_embeds: Tensor, max_new_tokens: int, eos_id: int, pad_id: int, uniforms: Tensor,
                          do_sample: bool = True, temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0,

@@ -112,42 +112,89 @@ _DP_SCRIPT = r"""
 import os, sys, json, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from icl_speech_text_llm_amd.inference.inference import run_inference, parse_args
+from icl_speech_text_llm_amd.runtime.salmonn import GenerateResult
 import icl_speech_text_llm_amd.models.custom_salmon as cs
 
-def fake_generate(self, samples):
+def fake_generate_ids(self, samples, want_first_logits=False):
     # CPU stand-in for the HIP generate: a deterministic function of the prompt (tests the DP plumbing only)
-    return [f"neutral {len(p) % 7}" for p in samples["prompt"]]
-cs.CustomSALMONN.generate_output = fake_generate
+    if os.environ.get("DP_FAIL") == "1" and int(os.environ.get("RANK", "0")) == 1 and self.batch_counter == 1:
+        self.batch_counter += 1
+        raise ValueError("injected failure of rank 1's second batch")
+    tok, V = self.llama_tokenizer, self.cfg.llama.vocab
+    rows = [tok(f"neutral {len(p) % 7}", add_special_tokens=False, return_tensors="pt")["input_ids"].reshape(-1).tolist()
+            + [tok.eos_token_id] for p in samples["prompt"]]
+    w = max(len(r) for r in rows)
+    toks = torch.tensor([r + [tok.pad_token_id] * (w - len(r)) for r in rows], dtype=torch.int64)
+    first = torch.stack([torch.arange(V, dtype=torch.float32) * 0.25 + (len(p) % 13) for p in samples["prompt"]])
+    self.batch_counter += 1
+    return GenerateResult(tokens=toks, first_logits=first)
+cs.CustomSALMONN.generate_ids = fake_generate_ids
 args = parse_args(["--peft_model_path", "", "--run_name", "dp", "--dataset_type", "voxceleb-hvb", "--device", "cpu",
                    "--arch", "tiny", "--synthetic_items", "5", "--batch_size", "2", "--num_workers", "0",
                    "--input_mode", "text_only", "--results_dir", sys.argv[2]])
 out = run_inference(args)
 if int(os.environ["RANK"]) == 0:
     json.dump({"n": len(out["results"]), "texts": [r["text"] for r in out["results"]],
-               "preds": [r["predicted_label"] for r in out["results"]]}, open(os.path.join(sys.argv[2], "summary.json"), "w"))
+               "preds": [r["predicted_label"] for r in out["results"]],
+               "label_logits": [r.get("first_step_label_logits") for r in out["results"]],
+               "missing": out["performance"]["missing_indices"], "failed": out["performance"]["failed_batches"]},
+              open(os.path.join(sys.argv[2], "summary.json"), "w"))
 """
 
 
+def _run_dp(script, out_dir, world, port, extra_env=None):
+    if world == 1:
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", **(extra_env or {}))
+        cmd = [sys.executable, str(script), ROOT, str(out_dir)]
+    else:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        env.update(extra_env or {})
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(out_dir)]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return json.load(open(os.path.join(out_dir, "summary.json")))
+
+
 def test_data_parallel_sharding_gloo_world2(tmp_path):
-    """N>1 path on CPU: 2 ranks over gloo shard the utterances i = rank (mod 2); rank 0 gathers all results in dataset order."""
-    import json
+    """N>1 path on CPU: 2 ranks over gloo shard the utterances i = rank (mod 2); ONE fixed-shape all-gather carries (dataset
+    index, generated ids, generated length, first-step label logits) and rank 0 decodes and re-orders by index.  Checked
+    against the single-process run: same texts, same predictions, same label logits, in dataset order — and with a batch
+    failing on rank 1 the surviving records keep their places and the lost indices are reported, not shifted over."""
     script = tmp_path / "dp.py"
     script.write_text(_DP_SCRIPT)
-    single = tmp_path / "w1"
-    multi = tmp_path / "w2"
-    single.mkdir(); multi.mkdir()
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    subprocess.run([sys.executable, str(script), ROOT, str(single)], check=True, env=env, timeout=300,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    env2 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                    "127.0.0.1", "--master-port", "29611", str(script), ROOT, str(multi)], check=True, env=env2, timeout=300,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    a = json.load(open(single / "summary.json"))
-    b = json.load(open(multi / "summary.json"))
-    assert a["n"] == b["n"] == 10
+    for d in ("w1", "w2", "w2f"):
+        (tmp_path / d).mkdir()
+    a = _run_dp(script, tmp_path / "w1", 1, 0)
+    b = _run_dp(script, tmp_path / "w2", 2, 29611)
+    assert a["n"] == b["n"] == 10 and a["missing"] == b["missing"] == [] and b["failed"] == 0
     assert a["texts"] == b["texts"] and a["preds"] == b["preds"]
-    assert any(f.endswith("_metrics.json") for f in os.listdir(multi))
+    assert a["label_logits"][0] and a["label_logits"] == b["label_logits"]       # bf16 slice of the first-step logits, by label
+    assert any(f.endswith("_metrics.json") for f in os.listdir(tmp_path / "w2"))
+    c = _run_dp(script, tmp_path / "w2f", 2, 29613, {"DP_FAIL": "1"})
+    assert c["failed"] == 1 and c["missing"] == [5, 7] and c["n"] == 8     # rank 1 holds 1,3,5,7,9: its 2nd batch is (5, 7)
+    keep = [i for i in range(10) if i not in (5, 7)]
+    assert c["texts"] == [a["texts"][i] for i in keep] and c["preds"] == [a["preds"][i] for i in keep]
+
+
+def test_row_packer_roundtrip_and_result_gather_layout():
+    """runtime/dp.py byte rows: every field 16-byte aligned, round trip exact for int64 / int32 / bf16 (odd vocabulary width),
+    zero-width logits allowed."""
+    import torch
+    from icl_speech_text_llm_amd.runtime.dp import RowPacker, result_packer
+    pk = result_packer(10, 32001)
+    assert pk.row_bytes % 16 == 0 and all(f[3] % 16 == 0 for f in pk.fields)
+    g = torch.Generator().manual_seed(0)
+    idx = torch.arange(5, dtype=torch.int64) * 7
+    ids = torch.randint(0, 32001, (5, 10), generator=g, dtype=torch.int32)
+    ln = torch.randint(1, 11, (5,), generator=g, dtype=torch.int32)
+    lg = torch.randn(5, 32001, generator=g).to(torch.bfloat16)
+    got = pk.unpack(pk.pack(pk.alloc(5, "cpu"), index=idx, gen_ids=ids, gen_len=ln, first_logits=lg))
+    assert torch.equal(got["index"], idx) and torch.equal(got["gen_ids"], ids) and torch.equal(got["gen_len"], ln)
+    assert torch.equal(got["first_logits"], lg)
+    pk0 = result_packer(4, 0)
+    got0 = pk0.unpack(pk0.pack(pk0.alloc(2, "cpu"), index=idx[:2], gen_ids=ids[:2, :4], gen_len=ln[:2],
+                               first_logits=torch.zeros(2, 0, dtype=torch.bfloat16)))
+    assert got0["first_logits"].shape == (2, 0) and torch.equal(got0["gen_ids"], ids[:2, :4])
 
 
 def test_dataset_pipeline_matches_reference_items(tmp_path):
