@@ -262,6 +262,7 @@ def run_inference(args) -> Dict[str, Any]:
             for r, i in enumerate(idx_l):
                 rows[i]["first_step_label_logits"] = dict(zip(label_names, ll[r].tolist()))
         results = [rows[i] for i in sorted(rows)]
+        label_logits = [r.get("first_step_label_logits") for r in results]
         if rank == 0:
             missing = sorted(set(range(total)) - set(rows))
             perf["missing_indices"] = missing
@@ -270,7 +271,7 @@ def run_inference(args) -> Dict[str, Any]:
                              missing[:20], " ..." if len(missing) > 20 else "")
             save_final_results(results, args, results_dir)
             tracker.log_summary()
-        return {"results": results, "performance": perf}
+        return {"results": results, "performance": perf, "label_logits": label_logits}
     except Exception as e:
         logger.error("Error during inference: %s", e)
         logger.debug(traceback.format_exc())
@@ -284,8 +285,14 @@ def save_final_results(results, args, results_dir):
     base = f"{args.run_name}_{args.dataset_type.replace(' ', '')}_{args.input_mode}_{args.fewshot_mode}_{args.num_examples}shots"
     if args.output_suffix:
         base += f"_{args.output_suffix}"
+    # the reference's result records carry exactly five keys (:350-356); the first-step label logits that the data-parallel
+    # gather brings along go to a file of their own, index-aligned with the results list
+    label_logits = [r.pop("first_step_label_logits", None) for r in results]
     with open(os.path.join(results_dir, f"{base}_results.json"), "w") as f:
         json.dump(results, f, indent=2)
+    if any(x is not None for x in label_logits):
+        with open(os.path.join(results_dir, f"{base}_label_logits.json"), "w") as f:
+            json.dump(label_logits, f)
     metrics = {}
     for dt in parse_dataset_types(args.dataset_type):
         rows = [r for r in results if r["dataset_type"] == dt.value]

@@ -51,7 +51,7 @@ def test_whisper_encoder(env):
     ref_f = om.whisper_encoder(sd, spec, cfg.whisper.n_heads, "speech_encoder.")
     eb, ef = _rel(got, ref_b), _rel(got, ref_f)
     print(f"whisper: rel err vs bf16-rounding oracle {eb:.2e}, vs fp32 oracle {ef:.2e}")
-    assert eb < 4e-3 and ef < 2e-2
+    assert eb < 2.5e-3 and ef < 6e-3            # measured on MI355X: 1.2e-3 / 2.7e-3
 
 
 def test_beats_encoder(env):
@@ -69,7 +69,7 @@ def test_beats_encoder(env):
         assert ref_b.shape[1] == T[i] and not pm.any()
         eb, ef = _rel(got[cu[i]:cu[i + 1]], ref_b[0]), _rel(got[cu[i]:cu[i + 1]], ref_f[0])
         print(f"beats[{i}] T={T[i]}: rel err vs bf16-rounding oracle {eb:.2e}, vs fp32 oracle {ef:.2e}")
-        assert eb < 6e-3 and ef < 3e-2
+        assert eb < 2e-4 and ef < 8e-3              # measured: 6.4e-5 / 3.7e-3
     # (b) padded-batch semantics (speech exemplars): both audios run at L with a key padding mask
     got, cu, T = rt.beats.forward(rt.ws, wav.to(DEV), [L, L], lens)
     ref_b, pm = om.beats_encoder(sd, wav, lens, prefix="beats.", n_heads=cfg.beats.n_heads, rnd=om.bf16_round)
@@ -78,7 +78,7 @@ def test_beats_encoder(env):
         valid = ~pm[i]
         eb = _rel(got[cu[i]:cu[i + 1]][valid], ref_b[i][valid])
         print(f"beats padded[{i}]: valid rows {int(valid.sum())}/{T[i]} rel err {eb:.2e}")
-        assert eb < 6e-3
+        assert eb < 2e-4                             # measured: 6.5e-5
 
 
 def test_encode_speech_full(env):
@@ -96,7 +96,7 @@ def test_encode_speech_full(env):
                                          beats_cfg=dict(n_heads=cfg.beats.n_heads), qformer_heads=cfg.qformer.n_heads)
         eb, ef = _rel(got[i], ref_b[0]), _rel(got[i], ref_f[0])
         print(f"encode_speech[{i}]: rel err vs bf16-rounding oracle {eb:.2e}, vs fp32 oracle {ef:.2e}")
-        assert eb < 8e-3 and ef < 3e-2
+        assert eb < 1.5e-3 and ef < 5e-3            # measured: 7.2e-4 / 2.2e-3
     # spectrogram supplied by the caller (the reference's batch dict) must give the same result as in-path K1
     spec_in = rt.log_mel(wav, lens).clone()
     got2 = rt.encode_speech(wav, lens, spectrogram=spec_in)
@@ -146,7 +146,7 @@ def test_llama_forward_logits_and_loss(env):
         eb, ef = _rel(g, lb[0]), _rel(g, lf[0])
         print(f"llama logits[{i}] S={S}: rel err vs bf16-rounding oracle {eb:.2e}, vs fp32 oracle {ef:.2e}; "
               f"max abs {float((g.cpu() - lb[0]).abs().max()):.2e} (|logit| max {float(lb.abs().max()):.2f})")
-        assert eb < 5e-3 and ef < 2e-2
+        assert eb < TOL_LOGITS_REL and ef < 1.2e-2   # measured: 3.7e-3 / 5.9e-3 (floor: bf16 P inside flash attention)
         shifted = torch.full((S,), -100, dtype=torch.int32)
         shifted[:-1] = labels[0, 1:].to(torch.int32)
         loss = rt.cross_entropy(g, shifted).cpu()
@@ -155,7 +155,7 @@ def test_llama_forward_logits_and_loss(env):
 
 
 # asserted bounds = ~2x the values measured on MI355X (printed by the tests)
-TOL_LOGITS_REL = 5e-3        # packed prefill / decode logits vs the bf16-rounding oracle, relative L2 per row
+TOL_LOGITS_REL = 6e-3        # packed prefill / decode logits vs the bf16-rounding oracle, relative L2 per row (measured 4.1e-3)
 
 
 def test_llama_generate_matches_oracle(env):

@@ -58,7 +58,8 @@ def test_get_speech_embeddings_matches_oracle_batch1(model):
     spec = torch.from_numpy(af.whisper_logmel(wav.numpy()))[None]
     ref = om.salmonn_encode_speech(sd, spec, wav[None], [n], cfg.whisper.n_heads, **kw)
     rel = float((sp[0].cpu() - ref[0]).norm() / ref[0].norm())
-    assert rel < 8e-3, rel
+    print(f"get_speech_embeddings main: rel {rel:.2e}")
+    assert rel < 1.5e-3, rel                     # measured on MI355X: ~7e-4
     # exemplar audio: the reference encodes the PADDED wav with its padding mask (custom_salmon.py:511-519)
     for e in range(2):
         ne = int(b["example_wav_lengths"][0, e])
@@ -66,7 +67,8 @@ def test_get_speech_embeddings_matches_oracle_batch1(model):
         spec = torch.from_numpy(af.whisper_logmel(wpad[:ne].numpy()))[None]
         ref = om.salmonn_encode_speech(sd, spec, wpad[None], [ne], cfg.whisper.n_heads, **kw)
         rel = float((ee[0][e].cpu() - ref[0]).norm() / ref[0].norm())
-        assert rel < 8e-3, (e, rel)
+        print(f"get_speech_embeddings exemplar {e}: rel {rel:.2e}")
+        assert rel < 1.5e-3, (e, rel)
 
 
 def test_forward_loss_logits_labels(model):
@@ -89,7 +91,8 @@ def test_forward_loss_logits_labels(model):
     full = torch.cat([wrapped[0].cpu(), llm.embed(tgt.input_ids[0])], 0)[None]
     ref_logits, ref_loss = llm.forward(full, labels.cpu())
     rel = float((logits.cpu() - ref_logits).norm() / ref_logits.norm())
-    assert rel < 6e-3, rel
+    print(f"plugin forward logits rel {rel:.2e}")
+    assert rel < 6e-3, rel                       # measured ~3.6e-3 (floor: bf16 P inside flash attention)
     assert abs(float(loss) - float(ref_loss)) < 5e-3 * max(1.0, abs(float(ref_loss)))
 
 
@@ -203,6 +206,7 @@ def test_sqa_two_audio_batches_match_oracle(model, tmp_path):
             full = torch.cat([want, llm.embed(tgt.input_ids[0])], 0)[None]
             ref_logits, ref_loss = llm.forward(full, out["labels"].cpu())
             rel = float((out["logits"].cpu() - ref_logits).norm() / ref_logits.norm())
+            print(f"sqa forward logits rel {rel:.2e}")
             assert rel < 6e-3, rel
             text = model.generate_output({k_: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k_, v in b.items()})
             assert len(text) == 1 and isinstance(text[0], str)
@@ -288,6 +292,7 @@ def test_pretrained_hf_folders_are_ingested(tmp_path):
         ref = llama(input_ids=ids).logits[0]
     got = out["logits"][0, :, :259].float().cpu()
     rel = float((got - ref).norm() / ref.norm())
+    print(f"plugin vs HF llama (fp32) logits rel {rel:.2e}")
     assert got.shape == ref.shape and rel < 2e-2, rel
     # Whisper encoder vs HF on a seeded spectrogram
     spec = torch.randn(1, 80, 3000) * 0.5

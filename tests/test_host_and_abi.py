@@ -136,7 +136,7 @@ out = run_inference(args)
 if int(os.environ["RANK"]) == 0:
     json.dump({"n": len(out["results"]), "texts": [r["text"] for r in out["results"]],
                "preds": [r["predicted_label"] for r in out["results"]],
-               "label_logits": [r.get("first_step_label_logits") for r in out["results"]],
+               "label_logits": out["label_logits"],
                "missing": out["performance"]["missing_indices"], "failed": out["performance"]["failed_batches"]},
               open(os.path.join(sys.argv[2], "summary.json"), "w"))
 """
