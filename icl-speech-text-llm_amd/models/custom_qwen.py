@@ -21,20 +21,18 @@ from ..runtime import synth
 from ..runtime.config import QwenAudioCfg
 from ..utils.tokenization import ByteTokenizer, Encoding
 from .base_model import BaseModel
-from .custom_salmon import _build_tree
+from .custom_salmon import PackedTreeModule
 
 logger = logging.getLogger(__name__)
 
 
-class QwenModule(nn.Module):
+class QwenModule(PackedTreeModule):
     """Parameter tree under HF Qwen2-Audio key names + the packed HIP runtime built from it on first use."""
 
     def __init__(self, cfg: QwenAudioCfg, device, seed: int = 0):
         super().__init__()
         self.cfg = cfg
-        self._device = torch.device(device)
-        _build_tree(self, synth.qwen_audio_state(cfg, seed=seed, device=self._device, dtype=torch.bfloat16))
-        self._runtime = None
+        self._init_tree(device, synth.qwen_audio_state(cfg, seed=seed, device=torch.device(device), dtype=torch.bfloat16))
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         from ..runtime.qwen import normalize_qwen_keys
@@ -45,21 +43,9 @@ class QwenModule(nn.Module):
         self._runtime = None
         return out
 
-    def _apply(self, fn, *a, **kw):
-        out = super()._apply(fn, *a, **kw)
-        self._runtime = None
-        try:
-            self._device = next(self.parameters()).device
-        except StopIteration:
-            pass
-        return out
-
-    @property
-    def runtime(self):
-        if self._runtime is None:
-            from ..runtime.qwen import QwenAudioRuntime
-            self._runtime = QwenAudioRuntime(self.cfg, self.state_dict(), device=self._device)
-        return self._runtime
+    def _build_runtime(self):
+        from ..runtime.qwen import QwenAudioRuntime
+        return QwenAudioRuntime(self.cfg, self.state_dict(), device=self._device)
 
 
 class QwenSpecialTokenizer(ByteTokenizer):

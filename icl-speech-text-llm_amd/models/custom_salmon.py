@@ -128,7 +128,50 @@ def _build_tree(root: nn.Module, tensors: Dict[str, torch.Tensor]):
         node.register_parameter(leaf, nn.Parameter(t, requires_grad=False))
 
 
-class SalmonnModule(nn.Module):
+class PackedTreeModule(nn.Module):
+    """A parameter tree under the checkpoint's own key names + the packed HIP runtime built from it on first use.
+
+    Residency: the runtime holds the weights in the layouts the kernels want (fused QKV / gate-up, decode-packed copies);
+    once it is built the tree is the *checkpoint image* only (``state_dict`` / ``load_state_dict`` / ``save_checkpoint``), so it
+    is moved to host memory and the GPU keeps ONE set of weights per layout in use (the tree + packed + decode-
+    packed used to sit on the device together, 40 GB at 7B).  Tensors the runtime shares with the tree without a copy (o_proj,
+    down_proj, embedding, lm_head are used in their checkpoint layout) stay alive on the device through the runtime's own
+    references.  ``.to(device)`` after that only re-targets the runtime; the tree stays on the host."""
+
+    offload_tree = True
+
+    def _init_tree(self, device, tensors):
+        self._device = torch.device(device)
+        _build_tree(self, tensors)
+        self._runtime = None
+
+    def _build_runtime(self):
+        raise NotImplementedError
+
+    def _apply(self, fn, *a, **kw):
+        probe = fn(torch.empty(0, device=self._device))
+        if self._runtime is not None and probe.device == self._device:
+            return self                          # nothing to move: the runtime already lives there
+        if probe.device.type == "cuda" and any(p.device.type == "cpu" for p in self.parameters()):
+            self._device, self._runtime = probe.device, None      # host-resident tree: packed straight to the new device
+            return self
+        out = super()._apply(fn, *a, **kw)
+        self._runtime = None
+        self._device = probe.device
+        return out
+
+    @property
+    def runtime(self):
+        if self._runtime is None:
+            self._runtime = self._build_runtime()
+            if self.offload_tree and self._device.type == "cuda":
+                for prm in self.parameters():
+                    if prm.device.type == "cuda":
+                        prm.data = prm.data.to("cpu")
+        return self._runtime
+
+
+class SalmonnModule(PackedTreeModule):
     """Stand-in for ``SALMONN.models.salmonn_org.SALMONN``: a parameter tree under the checkpoint's own key names
     (``speech_encoder.*``, ``beats.*``, ``ln_speech``, ``ln_audio``, ``speech_Qformer.bert.*``, ``speech_query_tokens``,
     ``speech_llama_proj.*``, ``llama_model.*``) plus the packed HIP runtime built from it on first use."""
@@ -136,9 +179,7 @@ class SalmonnModule(nn.Module):
     def __init__(self, cfg: SalmonnCfg, device, seed: int = 0):
         super().__init__()
         self.cfg = cfg
-        self._device = torch.device(device)
-        _build_tree(self, synth.salmonn_state(cfg, seed=seed, device=self._device, dtype=torch.bfloat16))
-        self._runtime = None
+        self._init_tree(device, synth.salmonn_state(cfg, seed=seed, device=torch.device(device), dtype=torch.bfloat16))
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         sd = normalize_keys(dict(state_dict))
@@ -148,21 +189,9 @@ class SalmonnModule(nn.Module):
         self._runtime = None   # re-pack on next use
         return result
 
-    def _apply(self, fn, *a, **kw):
-        out = super()._apply(fn, *a, **kw)
-        self._runtime = None
-        try:
-            self._device = next(self.parameters()).device
-        except StopIteration:
-            pass
-        return out
-
-    @property
-    def runtime(self):
-        if self._runtime is None:
-            from ..runtime.salmonn import SalmonnRuntime
-            self._runtime = SalmonnRuntime(self.cfg, self.state_dict(), device=self._device)
-        return self._runtime
+    def _build_runtime(self):
+        from ..runtime.salmonn import SalmonnRuntime
+        return SalmonnRuntime(self.cfg, self.state_dict(), device=self._device)
 
     def encode_speech(self, spectrogram=None, raw_wav=None, audio_padding_mask=None):
         """SALMONN.encode_speech signature (reference call: custom_salmon.py:550-554) -> (embeds [B,88,H], atts [B,88])."""
@@ -259,7 +288,9 @@ class CustomSALMONN(BaseModel):
         else:
             logger.warning("checkpoint %r not found: running on seeded synthetic weights", ckpt_path)
         self.speech_tag_start, self.speech_tag_end, self.speech_placeholder = "<Speech>", "</Speech>", "<SpeechHere>"
-        self.llama_model = self.salmonn.llama_model
+        # exposed as the reference does (models/custom_salmon.py:108), but NOT registered as a second child module: a child would be
+        # walked by .to() on its own and drag the host-resident checkpoint image of the decoder back onto the device
+        object.__setattr__(self, "llama_model", self.salmonn.llama_model)
         self.llama_tokenizer = tokenizer if tokenizer is not None else load_llama_tokenizer(llama_path, cfg.llama.vocab)
         self.input_processor = HipLogMelFeatureExtractor(self)
         self.batch_counter = 0
@@ -271,10 +302,7 @@ class CustomSALMONN(BaseModel):
 
     def to(self, *args, **kwargs):
         out = super().to(*args, **kwargs)
-        try:
-            self.device = next(self.parameters()).device
-        except StopIteration:
-            pass
+        self.device = self.salmonn._device       # where the runtime lives (the parameter tree may sit on the host)
         return out
 
     @property
