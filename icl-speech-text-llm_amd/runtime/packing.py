@@ -292,12 +292,12 @@ def pack_llama(sd: SD, cfg: LlamaCfg, device, prefix: str = "llama_model.", cons
         for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
             wqkv[j * h:(j + 1) * h, :h] = _take(sd, lp + f"self_attn.{n}.weight", consume).to(device=device, dtype=torch.bfloat16)
         lora_a = None
-        if r:   # K-augmentation: target t (one of q/k/v) gets its B in column block [h + i*r, h + (i+1)*r) of its own rows
+        if r:   # K-augmentation: target t (one of q/k/v) gets its B in column block [h + ti*r, h + (ti+1)*r) of its own rows
             a_rows = []
-            for i, tgt in enumerate(cfg.lora_targets):
+            for ti, tgt in enumerate(cfg.lora_targets):
                 j = ("q_proj", "k_proj", "v_proj").index(tgt)
                 a_rows.append(_take(sd, lp + f"self_attn.{tgt}.lora_A.weight", consume))
-                wqkv[j * h:(j + 1) * h, h + i * r:h + (i + 1) * r] = \
+                wqkv[j * h:(j + 1) * h, h + ti * r:h + (ti + 1) * r] = \
                     _take(sd, lp + f"self_attn.{tgt}.lora_B.weight", consume).to(device=device, dtype=torch.bfloat16)
             # the LoRA scale (alpha/r) is folded into A here so the down-projection can run as a plain GEMM
             lora_a = _bf(torch.cat(a_rows, 0).float() * cfg.lora_scale, device)
