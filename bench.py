@@ -533,7 +533,7 @@ def main():
         log(f"warmup step {s} done")
         if s == 0:
             first_tokens = toks[0].tolist()
-    for extra in range(max(0, 2 - args.warmup)):
+    for extra in range(max(0, 2 - args.warmup) if rt.use_graphs else 0):
         toks = step(0, gather=False)
         torch.cuda.synchronize()
         log(f"graph warm-up pass {extra} (untimed, not counted in --warmup) done")
