@@ -1,14 +1,14 @@
 #!/bin/bash
-# Same-box A/B of the prefill attention kernel variants (tools/attn_only.py); usage: tools/attn_ab.sh <outfile>
-out=${1:-gpurun_out/attn_ab.log}
+# Same-box A/B of prefill-attention builds / variants (tools/attn_only.py).  usage: tools/attn_ab.sh <outfile> [shapes...]
+out=${1:-gpurun_out/attn_ab.log}; shift
+shapes=${@:-whisper beats}
 : > $out
-run() { echo "--- $*" >> $out; env "$@" python tools/attn_only.py $SHAPE >> $out 2>&1; }
-for SHAPE in whisper beats beats_bias llama; do
-  export SHAPE
-  [ -f icl-speech-text-llm_amd/lib/libicl_hip_base.so ] && run ICL_LIB=icl-speech-text-llm_amd/lib/libicl_hip_base.so
-  run ICL_ATTN_PIPE=0 ICL_ATTN_NW=4
-  run ICL_ATTN_PIPE=0 ICL_ATTN_NW=8
-  run ICL_ATTN_PIPE=1 ICL_ATTN_NW=4
-  run ICL_ATTN_PIPE=1 ICL_ATTN_NW=8
+for SHAPE in $shapes; do
+  for lib in icl-speech-text-llm_amd/lib/libicl_hip*.so; do
+    for il in 0 1; do
+      echo "--- $SHAPE $lib ICL_ATTN_IL=$il" >> $out
+      ICL_ATTN_IL=$il ICL_LIB=$lib python tools/attn_only.py $SHAPE 2>&1 | grep "attn " >> $out
+    done
+  done
 done
 cat $out

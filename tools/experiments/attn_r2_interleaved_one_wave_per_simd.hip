@@ -1,0 +1,811 @@
+// attn.hip — fused (flash-style) attention forward for gfx950, head_dim 64 / 128, bf16 in/out.
+//
+// Structure (cdna_hip_programming.md Appendix B "Fused attention prefill", T10/T12/T14):
+//   * block = 4 waves, each wave owns 32 query rows of one (sequence, head); KV tiles of 64 keys.
+//   * swapped QK^T: S^T = K · Q^T on v_mfma_f32_32x32x16_bf16, so the query sits on the LANE and
+//     its scores sit in that lane's accumulator registers -> row max / row sum are in-register
+//     (one cross-half exchange), no LDS round trip for P.
+//   * O^T = V^T · P^T: the S^T accumulator registers 8s..8s+7 (converted to bf16) ARE the B operand
+//     of k-step s (guide §3 "An accumulator tile as the next MFMA's operand"); the matching,
+//     k-permuted V^T A-operand comes from two ds_read_b64_tr_b16 transposed reads of the
+//     row-major V tile.  The per-query rescale is then a per-lane scalar.
+//   * K/V tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB per wave-instruction, no VGPR round trip and no
+//     ds_write): tile t+1 is issued at the top of iteration t into the OTHER buffer, one vmcnt(0) + barrier per tile.
+//     The DMA destination is lane-linear, so rows are unpadded and bank conflicts are removed by swizzling on the SOURCE
+//     side: LDS slot s of row r holds global 16-B chunk s ^ f(r); K: f = (r>>1)&7 (D=64) / r&15 (D=128) makes the
+//     ds_read_b128 fragment reads conflict-free, V: f = ((r>>1)&1)<<2 (D=64) / (r&3)<<2 (D=128) does it for the
+//     transposed ds_read_b64_tr_b16 reads.
+// Variable-length packing (cu_seqlens), causal masking, a key-padding length per sequence and the
+// BEATs gated relative-position bias are handled in the score stage.
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+  const unsigned short* Q;
+  const unsigned short* K;
+  const unsigned short* V;
+  unsigned short* O;
+  const int* cu;
+  const int* kv_lens;
+  const float* rel_bias;
+  const float* rel_gate;
+  int64_t ldq, ldk, ldv, ldo;
+  int64_t kv_seq_stride, kv_head_stride;   // != 0: K/V live in a [seq][head][pos][D]-style cache (row stride ldk / ldv)
+  int n_heads, rel_span, n_qblocks;
+  float scale_log2e;
+};
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// fmaxf on MFMA outputs makes hipcc prepend a canonicalising v_max per operand (3 instructions per max of 2); the scores
+// are never signalling NaNs, so take the raw 3-input maximum: 16 instructions for the 32 scores of a tile instead of 57.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max2_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max32_raw(const f32x16& a, const f32x16& b) {
+  float m = max3_raw(a[0], a[1], a[2]);
+#pragma unroll
+  for (int r = 3; r + 1 < 16; r += 2) m = max3_raw(m, a[r], a[r + 1]);
+  m = max3_raw(m, a[15], b[0]);
+#pragma unroll
+  for (int r = 1; r + 1 < 16; r += 2) m = max3_raw(m, b[r], b[r + 1]);
+  return max2_raw(m, b[15]);
+}
+// maximum over the two half-waves (lane i <-> lane i + 32) on the vector port: v_permlane32_swap exchanges the halves, no LDS
+// round trip (ds_bpermute sits ~100 cycles deep in the softmax's dependency chain)
+__device__ __forceinline__ float xhalf_max(float v) {
+  const unsigned int u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return max2_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int D, bool CAUSAL, bool BIAS>
+__global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
+  // 32-query blocks per wave: at D = 64 two of them share every K and V fragment read, every staged byte and every
+  // barrier (the loop is issue-bound, not MFMA-bound); the gated-bias variant keeps one (measured: its longer per-score
+  // sequence wants the third wave per SIMD more than the sharing, 407 vs 385 TF/s on the BEATs shape)
+  constexpr int QB = (D == 64 && !BIAS) ? 2 : 1;
+  constexpr int BQ = 128 * QB;      // queries per workgroup
+  constexpr int ROWB = D * 2;       // bytes per K / V row in LDS (unpadded: LDS-DMA writes lane-linear)
+  constexpr int KS = D / 16;        // QK^T k-steps
+  constexpr int DB = D / 32;        // output d-blocks
+  constexpr int CPR = D / 8;        // 16-B chunks per row
+  constexpr int NCH = 64 * CPR / 256;  // LDS-DMA wave-instructions per wave per tensor (1 KiB each)
+  constexpr int RPI = 64 / CPR;        // rows per DMA instruction
+  constexpr int BUF = 2 * 64 * ROWB;   // one K tile + one V tile
+  constexpr int NBUF = D == 64 ? 3 : 2;   // ring depth: tiles are staged NBUF-1 iterations ahead (D=128: 2 x 32 KiB keeps 2 blocks/CU)
+  constexpr int AHEAD = NBUF - 1;
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF];   // ONE barrier per KV tile
+  // gated relative-position bias: per tile and q-block the 95 table entries a wave can touch (rel = key - query over
+  // 64 keys x 32 queries) are staged once into a wave-private LDS window; a score then costs one ds_read_b32 at
+  // base + immediate instead of clamp + 64-bit address + global gather
+  __shared__ float bias_win[BIAS ? 4 * QB * 128 : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hh = lane >> 5;
+  // XCD-aware decode of a 1-D grid: consecutive block ids are dispatched round-robin over the 8 XCDs, each with its own L2.
+  // Block b -> work item (b % 8) * ceil(n/8)-chunk + b / 8 (bijective), work items ordered q-block fastest: all q-blocks of
+  // one (sequence, head) run on ONE XCD back to back, so its K/V (re-read by every q-block) is fetched into one L2 once.
+  const int n_blocks = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = n_blocks >> 3, r8 = n_blocks & 7;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int qblk = item % p.n_qblocks;
+  const int head = (item / p.n_qblocks) % p.n_heads, seq = item / (p.n_qblocks * p.n_heads);
+  const int row0 = p.cu[seq];
+  const int len = p.cu[seq + 1] - row0;
+  const int qb = qblk * BQ;
+  if (qb >= len) return;
+  int kvlen = len;
+  if (p.kv_lens) kvlen = min(max(p.kv_lens[seq], 1), len);
+  const int kv_end = CAUSAL ? min(kvlen, qb + BQ) : kvlen;
+  const int n_tiles = (kv_end + 63) >> 6;
+
+  int qw[QB], qpos[QB];           // first query of each of this wave's q-blocks / this lane's query in it
+  bf16x8 qf[QB][KS];              // Q fragments (B operand of S^T = K Q^T): lane (q, hh) holds Q[q][16ks + 8hh .. +7]
+  float gate[QB];
+  const float* bias_row = nullptr;
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    qw[qi] = qb + (wave * QB + qi) * 32;
+    qpos[qi] = qw[qi] + ql;
+    const int qrow = min(qpos[qi], len - 1);
+    const unsigned short* qp = p.Q + (int64_t)(row0 + qrow) * p.ldq + head * D + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = *(const bf16x8*)(qp + ks * 16);
+    gate[qi] = 0.f;
+    if (BIAS) gate[qi] = p.rel_gate[(int64_t)(row0 + qrow) * p.n_heads + head] * LOG2E;
+  }
+  if (BIAS) bias_row = p.rel_bias + (int64_t)head * (2 * p.rel_span - 1) + (p.rel_span - 1);
+
+  // ---- staging: LDS-DMA with source-side swizzle --------------------------------------------------------
+  // DMA instruction j = wave * NCH + i of a tensor covers rows RPI*j .. RPI*j + RPI-1; lane l lands in row RPI*j + l / CPR,
+  // slot l % CPR, and fetches global chunk slot ^ f(row).  Row pointers advance by one tile per iteration; only a tile that
+  // crosses the end of the sequence takes the clamped form (rows past the end are masked, the read must stay in bounds).
+  auto f_k = [](int row) { return D == 64 ? (row >> 1) & 7 : row & 15; };
+  auto f_v = [](int row) { return D == 64 ? ((row >> 1) & 1) << 2 : (row & 3) << 2; };
+  // row 0 of this (sequence, head): packed rows [cu[seq] + j][head*D ..] of the fused QKV buffer, or — when the strides are
+  // given — rows [seq][head][j][..] of a KV cache (the prefill reads back what the QKV GEMM's epilogue appended)
+  const int64_t kv_off = p.kv_seq_stride ? (int64_t)seq * p.kv_seq_stride + (int64_t)head * p.kv_head_stride : -1;
+  const unsigned short* kbase = kv_off >= 0 ? p.K + kv_off : p.K + (int64_t)row0 * p.ldk + head * D;
+  const unsigned short* vbase = kv_off >= 0 ? p.V + kv_off : p.V + (int64_t)row0 * p.ldv + head * D;
+  const unsigned short* kptr[NCH];
+  const unsigned short* vptr[NCH];
+  int srow[NCH], kch[NCH], vch[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int j = wave * NCH + i;
+    srow[i] = RPI * j + lane / CPR;
+    kch[i] = (lane % CPR) ^ f_k(srow[i]);
+    vch[i] = (lane % CPR) ^ f_v(srow[i]);
+    kptr[i] = kbase + (int64_t)srow[i] * p.ldk + kch[i] * 8;
+    vptr[i] = vbase + (int64_t)srow[i] * p.ldv + vch[i] * 8;
+  }
+  const int64_t kstep = 64 * p.ldk, vstep = 64 * p.ldv;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto stage_tile = [&](int t, int buf) {
+    const int k0 = t * 64;
+    char* k_w = lds + buf * BUF + wave * NCH * 1024;
+    char* v_w = k_w + 64 * ROWB;
+    if (k0 + 64 <= len) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(kptr[i] + (int64_t)t * kstep), (lptr_t)(k_w + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vptr[i] + (int64_t)t * vstep), (lptr_t)(v_w + i * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int64_t grow = min(k0 + srow[i], len - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(kbase + grow * p.ldk + kch[i] * 8), (lptr_t)(k_w + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vbase + grow * p.ldv + vch[i] * 8), (lptr_t)(v_w + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 o_acc[QB][DB];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    m_run[qi] = NEG_BIG;
+    l_run[qi] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[qi][d][r] = 0.f;
+  }
+
+  // K fragment reads: row kb*32 + ql, logical chunk 2*ks + hh -> physical chunk ^ f_k(row) (f_k(row + 32) = f_k(row))
+  int k_off[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_off[ks] = ql * ROWB + (((2 * ks + hh) ^ f_k(ql)) << 4);
+  // transposed V reads: lane i of a 16-lane group reads row (i>>2) [+4*hh, +8 for the second read], logical chunk
+  // 4*d + 2*((lane>>4)&1) + ((lane&3)>>1), half (lane&1); the rows' f_v depends only on (i>>2)
+  int tr_off[DB];
+  {
+    const int q = (lane & 15) >> 2;
+    const int c2 = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+      tr_off[d] = (4 * hh + q) * ROWB + (((4 * d + c2) ^ f_v(q)) << 4) + (lane & 1) * 8;
+  }
+
+  // counted waits: the AHEAD-1 youngest tiles (2*NCH LDS-DMA instructions each) stay in flight across the barrier
+  auto wait_oldest_tile = [&]() {
+    if constexpr (AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (NCH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  };
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a) stage_tile(min(a, n_tiles - 1), a);
+  wait_oldest_tile();
+  __syncthreads();
+  int cur = 0;            // ring slot of tile t
+
+  for (int t = 0; t < n_tiles; ++t) {
+    // unconditional (the last iteration stages its own tile again, into the idle buffer): a conditional issue makes hipcc's
+    // waitcnt pass merge the two paths pessimistically
+    int nxt = cur + AHEAD;
+    if (nxt >= NBUF) nxt -= NBUF;
+    stage_tile(min(t + AHEAD, n_tiles - 1), nxt);   // that slot held tile t-1: last read in iteration t-1 (barrier passed)
+    const int k0 = t * 64;
+    const char* k_lds = lds + cur * BUF;
+    const char* v_lds = k_lds + 64 * ROWB;
+    // wave-uniform: which of this wave's q-blocks see a key of this tile?
+    bool active[QB];
+    bool any_active = false;
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+      active[qi] = !CAUSAL || (k0 <= qw[qi] + 31);
+      any_active |= active[qi];
+    }
+    if (any_active) {
+      // ---- S^T = K Q^T: every K fragment is read once and feeds all q-blocks --------------------------------
+      f32x16 s_acc[QB][2];
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_acc[qi][kb][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const char* kp = k_lds + kb * 32 * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(kp + k_off[ks]);
+#pragma unroll
+          for (int qi = 0; qi < QB; ++qi)
+            if (active[qi]) s_acc[qi][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][ks], s_acc[qi][kb], 0, 0, 0);
+        }
+      }
+      // ---- scores -> base-2 logits, bias, mask, online softmax; per q-block ---------------------------------------
+      bf16x8 pf[QB][2][2];
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi) {
+        if (!active[qi]) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) pf[qi][kb][h2][e] = (__bf16)0.f;
+          continue;
+        }
+        // need_mask is wave-uniform: interior tiles take the branch-free fast path (raw v_exp_f32, one FMA per score)
+        const bool need_mask = __builtin_amdgcn_readfirstlane((int)((k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw[qi]))));
+        float psum = 0.f, alpha;
+        if (!BIAS && !need_mask) {
+          float tmax = max32_raw(s_acc[qi][0], s_acc[qi][1]);
+          tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;   // scale > 0: max commutes with the scaling
+          const float m_new = max2_raw(m_run[qi], tmax);
+          alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+          m_run[qi] = m_new;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[qi][kb][r], p.scale_log2e, -m_new));
+              psum += e;
+              pf[qi][kb][r >> 3][r & 7] = (__bf16)e;
+            }
+        } else {
+          float tmax;
+          const float* win = nullptr;
+          if (BIAS) {
+            float* w = bias_win + (wave * QB + qi) * 128;
+            const int base_rel = k0 - qw[qi] - 31;          // window index i <-> rel = base_rel + i, i in [0, 95)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int rel = max(-(p.rel_span - 1), min(p.rel_span - 1, base_rel + lane + 64 * i));
+              w[lane + 64 * i] = bias_row[rel];
+            }
+            __builtin_amdgcn_wave_barrier();                 // same wave, in-order LDS queue: the reads below see the writes
+            win = w + (4 * hh - ql + 31);
+          }
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              float v = s_acc[qi][kb][r] * p.scale_log2e;
+              if (BIAS) v = fmaf(gate[qi], win[kb * 32 + (r & 3) + 8 * (r >> 2)], v);
+              if (need_mask) {
+                const bool ok = (key < kvlen) && (!CAUSAL || key <= qpos[qi]);
+                v = ok ? v : NEG_BIG;
+              }
+              s_acc[qi][kb][r] = v;
+            }
+          }
+          tmax = max32_raw(s_acc[qi][0], s_acc[qi][1]);
+          tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64));
+          const float m_new = max2_raw(m_run[qi], tmax);
+          alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+          m_run[qi] = m_new;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float e = __builtin_amdgcn_exp2f(s_acc[qi][kb][r] - m_new);
+              if (need_mask) e = (s_acc[qi][kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
+              psum += e;
+              pf[qi][kb][r >> 3][r & 7] = (__bf16)e;
+            }
+          }
+        }
+        l_run[qi] = l_run[qi] * alpha + psum;
+        // the running maximum settles after the first tiles: skip the rescale when no query of the wave moved (x * 1.0f is exact)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+          for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[qi][d][r] *= alpha;
+        }
+      }
+      // ---- O^T += V^T P^T: every transposed V fragment is read once and feeds all q-blocks ----------------------------
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const char* vp = v_lds + (kb * 32 + 16 * s) * ROWB + tr_off[d];
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * ROWB));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+              if (active[qi]) o_acc[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][kb][s], o_acc[qi][d], 0, 0, 0);
+          }
+        }
+      }
+    }
+    wait_oldest_tile();   // this wave's share of tile t+1 has landed
+    __syncthreads();
+    cur = cur + 1 == NBUF ? 0 : cur + 1;
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l -------------------------------------------------------------
+  // A lane owns one query ROW, so direct stores are 8-B pieces at a row stride: every store instruction touches 64 cache
+  // lines.  The K/V ring is dead after the loop's last barrier: each wave transposes its rows through a private LDS region
+  // and stores whole head-rows (D * 2 bytes = one or two full lines), 16 B per lane.
+  float inv[QB];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+    inv[qi] = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  }
+  const bool rows16 = (((uintptr_t)p.O | (uintptr_t)(p.ldo * 2)) & 15) == 0;
+  if (rows16) {
+    constexpr int PITCH = D * 2 + 16;
+    constexpr int LPR = D * 2 / 16, RPI = 64 / LPR;     // lanes per row, rows per store instruction
+    char* stg = lds + wave * (QB * 32 * PITCH);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          *(u32x2*)(stg + (qi * 32 + ql) * PITCH + d0 * 2) =
+              u32x2{pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                    pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+        }
+    __builtin_amdgcn_wave_barrier();                    // same wave, in-order LDS queue
+#pragma unroll
+    for (int it = 0; it < QB * 32 / RPI; ++it) {
+      const int row = it * RPI + lane / LPR, cc = lane % LPR;
+      const int q = qw[row >> 5] + (row & 31);
+      const u32x4 v = *(const u32x4*)(stg + row * PITCH + cc * 16);
+      if (q < len) *(u32x4*)(p.O + (int64_t)(row0 + q) * p.ldo + head * D + cc * 8) = v;
+    }
+    return;
+  }
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    if (qpos[qi] < len) {
+      unsigned short* op = p.O + (int64_t)(row0 + qpos[qi]) * p.ldo + head * D;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          u32x2 pk = {pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                      pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+          *(u32x2*)(op + d0) = pk;
+        }
+      }
+    }
+  }
+}
+
+
+// ======================================================================================================================
+// D = 64, non-causal, no bias (Whisper / Qwen2-Audio encoder; BEATs without its bias): MFMA and softmax interleaved by hand
+// inside ONE wave per SIMD.
+//
+// Measured on MI355X (tools/ubench/overlap.hip, profiles/r02_ubench_mfma_valu_overlap.txt): the MFMA stream of one wave and
+// the VALU stream of ANOTHER wave on the same SIMD do not overlap at all (18.0 ms = 5.7 + 12.3), and two VALU waves share one
+// issue port (23.5 = 2 x 11.7) — a second wave per SIMD buys latency hiding, not throughput.  What does overlap is a VALU
+// instruction placed behind an MFMA in the SAME wave's stream (14.3 ms for the same work): the MFMA then costs its ~8 issue
+// cycles instead of its 32 pipe cycles.  attn_fwd_kernel<64> above runs QK^T, softmax, PV as three separate phases at two
+// waves per SIMD, and its time is the SUM of the parts (ablations in profiles/r02_attn_ablations.log: MFMAs 0.52 ms +
+// softmax 0.30 + staging 0.17 + rest 0.17 = 1.16 ms).  Here each wave owns the SIMD (launch bound 1 workgroup per CU, up to
+// 512 registers) and its two 32-query blocks run half a phase apart, every MFMA of one block followed by a slice of the
+// other block's softmax, with all MFMA operands already in registers (K and V fragments are read once per tile and shared by
+// both blocks) so no LDS wait sits inside the interleaved sections:
+//      A: K frags -> regs, S0 = K Q0^T (8 MFMA), V frags -> regs
+//      B: S1 = K Q1^T (8 MFMA)      ||  softmax(S0) -> P0        (8 slices)
+//      C: O0 += V^T P0^T (8 MFMA)   ||  softmax(S1) -> P1
+//      D: O1 += V^T P1^T (8 MFMA)
+// sched_barrier(0) pins the textual order between slices (there are no memory operations inside B and C for the compiler
+// to schedule around).  Tiles that need a mask (the trailing partial tile) take the plain three-phase path.
+// ======================================================================================================================
+__global__ __launch_bounds__(256, 1) void attn64_il_kernel(AttnParams p) {
+  constexpr int D = 64, QB = 2, BQ = 256, ROWB = 128, KS = 4, DB = 2, CPR = 8, NCH = 2, RPI = 8;
+  constexpr int BUF = 2 * 64 * ROWB;     // one K tile + one V tile
+  constexpr int NBUF = 4, AHEAD = 3;     // one workgroup per CU: 64 KiB ring, tiles staged three iterations ahead
+  constexpr int STG = 4 * QB * 32 * (D * 2 + 16);
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF > STG ? NBUF * BUF : STG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int n_blocks = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = n_blocks >> 3, r8 = n_blocks & 7;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int qblk = item % p.n_qblocks;
+  const int head = (item / p.n_qblocks) % p.n_heads, seq = item / (p.n_qblocks * p.n_heads);
+  const int row0 = p.cu[seq];
+  const int len = p.cu[seq + 1] - row0;
+  const int qb = qblk * BQ;
+  if (qb >= len) return;
+  int kvlen = len;
+  if (p.kv_lens) kvlen = min(max(p.kv_lens[seq], 1), len);
+  const int n_tiles = (kvlen + 63) >> 6;
+
+  int qw[QB], qpos[QB];
+  bf16x8 qf[QB][KS];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    qw[qi] = qb + (wave * QB + qi) * 32;
+    qpos[qi] = qw[qi] + ql;
+    const int qrow = min(qpos[qi], len - 1);
+    const unsigned short* qp = p.Q + (int64_t)(row0 + qrow) * p.ldq + head * D + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  // ---- staging: LDS-DMA with source-side swizzle (images of attn_fwd_kernel<64>) ------------------------------------
+  auto f_k = [](int row) { return (row >> 1) & 7; };
+  auto f_v = [](int row) { return ((row >> 1) & 1) << 2; };
+  const int64_t kv_off = p.kv_seq_stride ? (int64_t)seq * p.kv_seq_stride + (int64_t)head * p.kv_head_stride : -1;
+  const unsigned short* kbase = kv_off >= 0 ? p.K + kv_off : p.K + (int64_t)row0 * p.ldk + head * D;
+  const unsigned short* vbase = kv_off >= 0 ? p.V + kv_off : p.V + (int64_t)row0 * p.ldv + head * D;
+  const unsigned short* kptr[NCH];
+  const unsigned short* vptr[NCH];
+  int srow[NCH], kch[NCH], vch[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int j = wave * NCH + i;
+    srow[i] = RPI * j + lane / CPR;
+    kch[i] = (lane % CPR) ^ f_k(srow[i]);
+    vch[i] = (lane % CPR) ^ f_v(srow[i]);
+    kptr[i] = kbase + (int64_t)srow[i] * p.ldk + kch[i] * 8;
+    vptr[i] = vbase + (int64_t)srow[i] * p.ldv + vch[i] * 8;
+  }
+  const int64_t kstep = 64 * p.ldk, vstep = 64 * p.ldv;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto stage_tile = [&](int t, int buf) {
+    const int k0 = t * 64;
+    char* k_w = lds + buf * BUF + wave * NCH * 1024;
+    char* v_w = k_w + 64 * ROWB;
+    if (k0 + 64 <= len) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(kptr[i] + (int64_t)t * kstep), (lptr_t)(k_w + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vptr[i] + (int64_t)t * vstep), (lptr_t)(v_w + i * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int64_t grow = min(k0 + srow[i], len - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(kbase + grow * p.ldk + kch[i] * 8), (lptr_t)(k_w + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vbase + grow * p.ldv + vch[i] * 8), (lptr_t)(v_w + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 o_acc[QB][DB];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    m_run[qi] = NEG_BIG;
+    l_run[qi] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[qi][d][r] = 0.f;
+  }
+  int k_off[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_off[ks] = ql * ROWB + (((2 * ks + hh) ^ f_k(ql)) << 4);
+  int tr_off[DB];
+  {
+    const int q = (lane & 15) >> 2;
+    const int c2 = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) tr_off[d] = (4 * hh + q) * ROWB + (((4 * d + c2) ^ f_v(q)) << 4) + (lane & 1) * 8;
+  }
+  const float c = p.scale_log2e;
+
+  auto wait_oldest_tile = [&]() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * 2 * NCH) : "memory"); };
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a) stage_tile(min(a, n_tiles - 1), a);
+  wait_oldest_tile();
+  __syncthreads();
+  int cur = 0;
+
+  // one slice (j = 0..7) of the online softmax of a 32-query x 64-key score tile: slices 0/1 reduce the two accumulators
+  // to their maxima (independent chains), slice 2 updates the running maximum, slices 3..7 exponentiate 7+7+6+6+6 scores
+  struct SmState { float t0, t1, m_new, alpha, ps0, ps1; };
+  auto sm_slice = [&](const int j, const int qi, const f32x16 (&s)[2], bf16x8 (&pf)[2][2], SmState& st) {
+    if (j == 0 || j == 1) {
+      const f32x16& a = s[j];
+      float m = max3_raw(a[0], a[1], a[2]);
+#pragma unroll
+      for (int r = 3; r + 1 < 16; r += 2) m = max3_raw(m, a[r], a[r + 1]);
+      m = max2_raw(m, a[15]);
+      if (j == 0) st.t0 = m; else st.t1 = m;
+    } else if (j == 2) {
+      const float tmax = xhalf_max(max2_raw(st.t0, st.t1)) * c;
+      st.m_new = max2_raw(m_run[qi], tmax);
+      st.alpha = __builtin_amdgcn_exp2f(m_run[qi] - st.m_new);
+      m_run[qi] = st.m_new;
+      st.ps0 = 0.f;
+      st.ps1 = 0.f;
+    } else {
+      constexpr int first[6] = {0, 7, 14, 20, 26, 32};
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        if (i < first[j - 3] || i >= first[j - 2]) continue;
+        const int kb = i >> 4, r = i & 15;
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -st.m_new));
+        if (i & 1) st.ps1 += e; else st.ps0 += e;
+        pf[kb][r >> 3][r & 7] = (__bf16)e;
+      }
+      if (j == 7) l_run[qi] = l_run[qi] * st.alpha + (st.ps0 + st.ps1);
+    }
+  };
+  auto rescale = [&](int qi, float alpha) {
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[qi][d][r] *= alpha;
+    }
+  };
+
+  for (int t = 0; t < n_tiles; ++t) {
+    int nxt = cur + AHEAD;
+    if (nxt >= NBUF) nxt -= NBUF;
+    stage_tile(min(t + AHEAD, n_tiles - 1), nxt);
+    const int k0 = t * 64;
+    const char* k_lds = lds + cur * BUF;
+    const char* v_lds = k_lds + 64 * ROWB;
+    const bool need_mask = k0 + 64 > kvlen;     // wave-uniform (scalar)
+
+    // ---- A: fragments to registers, S0 ------------------------------------------------------------------------------
+    bf16x8 kf[2][KS];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const bf16x8*)(k_lds + kb * 32 * ROWB + k_off[ks]);
+    bf16x8 vf[DB][2][2];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const char* vp = v_lds + (kb * 32 + 16 * s2) * ROWB + tr_off[d];
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * ROWB));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          vf[d][kb][s2] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    f32x16 s0[2], s1[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[kb][r] = 0.f; s1[kb][r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s0[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[0][ks], s0[kb], 0, 0, 0);
+
+    bf16x8 p0[2][2], p1[2][2];
+    if (!need_mask) {
+      SmState st0, st1;
+      // ---- B: S1 MFMAs, each followed by a slice of softmax(S0) -------------------------------------------------------
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s1[j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j >> 2][j & 3], qf[1][j & 3], s1[j >> 2], 0, 0, 0);
+        sm_slice(j, 0, s0, p0, st0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)      // P0 is used behind the rescale branch: keep its 32 exp + 16 cvt in THIS block
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) asm volatile("" : "+v"(p0[kb][h2]));
+      rescale(0, st0.alpha);
+      // ---- C: O0 MFMAs, each followed by a slice of softmax(S1) -------------------------------------------------------
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = j >> 2, kb = (j >> 1) & 1, s2 = j & 1;
+        o_acc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][kb][s2], p0[kb][s2], o_acc[0][d], 0, 0, 0);
+        sm_slice(j, 1, s1, p1, st1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) asm volatile("" : "+v"(p1[kb][h2]));
+      rescale(1, st1.alpha);
+    } else {
+      // ---- masked tile (the trailing partial one): plain phases --------------------------------------------------------
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s1[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[1][ks], s1[kb], 0, 0, 0);
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi) {
+        f32x16 (&s)[2] = qi == 0 ? s0 : s1;
+        bf16x8 (&pf)[2][2] = qi == 0 ? p0 : p1;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            s[kb][r] = key < kvlen ? s[kb][r] * c : NEG_BIG;
+          }
+        const float tmax = xhalf_max(max32_raw(s[0], s[1]));
+        const float m_new = max2_raw(m_run[qi], tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+        m_run[qi] = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+            e = (s[kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
+            psum += e;
+            pf[kb][r >> 3][r & 7] = (__bf16)e;
+          }
+        l_run[qi] = l_run[qi] * alpha + psum;
+        rescale(qi, alpha);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = j >> 2, kb = (j >> 1) & 1, s2 = j & 1;
+        o_acc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][kb][s2], p0[kb][s2], o_acc[0][d], 0, 0, 0);
+      }
+    }
+    // ---- D: O1 MFMAs ----------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = j >> 2, kb = (j >> 1) & 1, s2 = j & 1;
+      o_acc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][kb][s2], p1[kb][s2], o_acc[1][d], 0, 0, 0);
+    }
+    wait_oldest_tile();
+    __syncthreads();
+    cur = cur + 1 == NBUF ? 0 : cur + 1;
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l, whole rows through a wave-private LDS region ----------------------------------
+  float inv[QB];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+    inv[qi] = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the re-staged tail tiles still in flight target the ring
+  __syncthreads();
+  const bool rows16 = (((uintptr_t)p.O | (uintptr_t)(p.ldo * 2)) & 15) == 0;
+  if (rows16) {
+    constexpr int PITCH = D * 2 + 16;
+    constexpr int LPR = D * 2 / 16, RPS = 64 / LPR;
+    char* stg = lds + wave * (QB * 32 * PITCH);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          *(u32x2*)(stg + (qi * 32 + ql) * PITCH + d0 * 2) =
+              u32x2{pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                    pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < QB * 32 / RPS; ++it) {
+      const int row = it * RPS + lane / LPR, cc = lane % LPR;
+      const int q = qw[row >> 5] + (row & 31);
+      const u32x4 v = *(const u32x4*)(stg + row * PITCH + cc * 16);
+      if (q < len) *(u32x4*)(p.O + (int64_t)(row0 + q) * p.ldo + head * D + cc * 8) = v;
+    }
+    return;
+  }
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    if (qpos[qi] < len) {
+      unsigned short* op = p.O + (int64_t)(row0 + qpos[qi]) * p.ldo + head * D;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          *(u32x2*)(op + d0) = u32x2{pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                                     pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+        }
+    }
+  }
+}
+
+template <int D>
+int launch_attn(const AttnParams& p, const icl_attn_args* a, hipStream_t stream) {
+  const int bq = (D == 64 && !a->rel_bias) ? 256 : 128;   // queries per workgroup (QB in the kernel)
+  dim3 grid(((a->max_seqlen + bq - 1) / bq) * a->n_heads * a->n_seqs, 1, 1);
+  const bool bias = a->rel_bias != nullptr;
+  if (a->causal) {
+    if (bias)
+      hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<D, true, false>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (bias)
+      hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<D, false, false>), grid, dim3(256), 0, stream, p);
+  }
+  ICL_CHECK_LAUNCH("icl_attn_fwd_bf16");
+  return ICL_OK;
+}
+
+}  // namespace
+
+extern "C" int icl_attn_fwd_bf16(const icl_attn_args* a, void* stream) {
+  ICL_CHECK_ARG(a != nullptr, "icl_attn_fwd_bf16: args is NULL");
+  ICL_CHECK_ARG(a->Q && a->K && a->V && a->O && a->cu_seqlens, "icl_attn_fwd_bf16: NULL pointer");
+  ICL_CHECK_ARG(a->head_dim == 64 || a->head_dim == 128, "icl_attn_fwd_bf16: head_dim=%d (only 64 and 128)", a->head_dim);
+  ICL_CHECK_ARG(a->n_seqs > 0 && a->n_seqs <= 65535 && a->n_heads > 0 && a->n_heads <= 65535 && a->max_seqlen > 0,
+                "icl_attn_fwd_bf16: bad n_seqs/n_heads/max_seqlen");
+  ICL_CHECK_ARG(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0,
+                "icl_attn_fwd_bf16: leading dimensions must be multiples of 8 (ldo: 4)");
+  ICL_CHECK_ARG(((uintptr_t)a->Q & 15) == 0 && ((uintptr_t)a->K & 15) == 0 && ((uintptr_t)a->V & 15) == 0 &&
+                    ((uintptr_t)a->O & 7) == 0,
+                "icl_attn_fwd_bf16: Q/K/V must be 16-byte and O 8-byte aligned");
+  ICL_CHECK_ARG((a->rel_bias == nullptr) == (a->rel_gate == nullptr), "icl_attn_fwd_bf16: rel_bias and rel_gate go together");
+  if (a->rel_bias) ICL_CHECK_ARG(a->rel_span >= 1, "icl_attn_fwd_bf16: rel_span must be >= 1");
+  AttnParams p;
+  p.Q = (const unsigned short*)a->Q;
+  p.K = (const unsigned short*)a->K;
+  p.V = (const unsigned short*)a->V;
+  p.O = (unsigned short*)a->O;
+  p.cu = a->cu_seqlens;
+  p.kv_lens = a->kv_lens;
+  p.rel_bias = a->rel_bias;
+  p.rel_gate = a->rel_gate;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+  ICL_CHECK_ARG((a->kv_seq_stride == 0) == (a->kv_head_stride == 0) && a->kv_seq_stride >= 0 && a->kv_head_stride >= 0 &&
+                    a->kv_seq_stride % 8 == 0 && a->kv_head_stride % 8 == 0,
+                "icl_attn_fwd_bf16: kv_seq_stride / kv_head_stride must both be 0 or both positive multiples of 8");
+  p.kv_seq_stride = a->kv_seq_stride; p.kv_head_stride = a->kv_head_stride;
+  p.n_heads = a->n_heads;
+  p.rel_span = a->rel_span;
+  const int bq = (a->head_dim == 64 && !a->rel_bias) ? 256 : 128;
+  p.n_qblocks = (a->max_seqlen + bq - 1) / bq;
+  p.scale_log2e = a->scale * LOG2E;
+  static const int il = [] { const char* e = getenv("ICL_ATTN_IL"); return e ? atoi(e) : 1; }();
+  if (il && a->head_dim == 64 && !a->causal && !a->rel_bias) {     // bq = 256 here as well
+    hipLaunchKernelGGL(attn64_il_kernel, dim3(p.n_qblocks * a->n_heads * a->n_seqs), dim3(256), 0, (hipStream_t)stream, p);
+    ICL_CHECK_LAUNCH("icl_attn_fwd_bf16");
+    return ICL_OK;
+  }
+  return a->head_dim == 64 ? launch_attn<64>(p, a, (hipStream_t)stream) : launch_attn<128>(p, a, (hipStream_t)stream);
+}

@@ -1,0 +1,848 @@
+// attn.hip — fused (flash-style) attention forward for gfx950, head_dim 64 / 128, bf16 in/out.
+//
+// Structure (cdna_hip_programming.md Appendix B "Fused attention prefill", T10/T12/T14):
+//   * block = 4 waves, each wave owns 32 query rows of one (sequence, head); KV tiles of 64 keys.
+//   * swapped QK^T: S^T = K · Q^T on v_mfma_f32_32x32x16_bf16, so the query sits on the LANE and
+//     its scores sit in that lane's accumulator registers -> row max / row sum are in-register
+//     (one cross-half exchange), no LDS round trip for P.
+//   * O^T = V^T · P^T: the S^T accumulator registers 8s..8s+7 (converted to bf16) ARE the B operand
+//     of k-step s (guide §3 "An accumulator tile as the next MFMA's operand"); the matching,
+//     k-permuted V^T A-operand comes from two ds_read_b64_tr_b16 transposed reads of the
+//     row-major V tile.  The per-query rescale is then a per-lane scalar.
+//   * K/V tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB per wave-instruction, no VGPR round trip and no
+//     ds_write): tile t+1 is issued at the top of iteration t into the OTHER buffer, one vmcnt(0) + barrier per tile.
+//     The DMA destination is lane-linear, so rows are unpadded and bank conflicts are removed by swizzling on the SOURCE
+//     side: LDS slot s of row r holds global 16-B chunk s ^ f(r); K: f = (r>>1)&7 (D=64) / r&15 (D=128) makes the
+//     ds_read_b128 fragment reads conflict-free, V: f = ((r>>1)&1)<<2 (D=64) / (r&3)<<2 (D=128) does it for the
+//     transposed ds_read_b64_tr_b16 reads.
+// Variable-length packing (cu_seqlens), causal masking, a key-padding length per sequence and the
+// BEATs gated relative-position bias are handled in the score stage.
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+  const unsigned short* Q;
+  const unsigned short* K;
+  const unsigned short* V;
+  unsigned short* O;
+  const int* cu;
+  const int* kv_lens;
+  const float* rel_bias;
+  const float* rel_gate;
+  int64_t ldq, ldk, ldv, ldo;
+  int64_t kv_seq_stride, kv_head_stride;   // != 0: K/V live in a [seq][head][pos][D]-style cache (row stride ldk / ldv)
+  int n_heads, rel_span, n_qblocks;
+  float scale_log2e;
+};
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// fmaxf on MFMA outputs makes hipcc prepend a canonicalising v_max per operand (3 instructions per max of 2); the scores
+// are never signalling NaNs, so take the raw 3-input maximum: 16 instructions for the 32 scores of a tile instead of 57.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max2_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max32_raw(const f32x16& a, const f32x16& b) {
+  float m = max3_raw(a[0], a[1], a[2]);
+#pragma unroll
+  for (int r = 3; r + 1 < 16; r += 2) m = max3_raw(m, a[r], a[r + 1]);
+  m = max3_raw(m, a[15], b[0]);
+#pragma unroll
+  for (int r = 1; r + 1 < 16; r += 2) m = max3_raw(m, b[r], b[r + 1]);
+  return max2_raw(m, b[15]);
+}
+// maximum over the two half-waves (lane i <-> lane i + 32) on the vector port: v_permlane32_swap exchanges the halves, no LDS
+// round trip (ds_bpermute sits ~100 cycles deep in the softmax's dependency chain)
+__device__ __forceinline__ float xhalf_max(float v) {
+  const unsigned int u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return max2_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int D, bool CAUSAL, bool BIAS, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : ((D == 64 && BIAS) ? 3 : 2)) void attn_fwd_kernel(AttnParams p) {
+  // 32-query blocks per wave: at D = 64 two of them share every K and V fragment read, every staged byte and every
+  // barrier (the loop is issue-bound, not MFMA-bound); the gated-bias variant keeps one (measured: its longer per-score
+  // sequence wants the third wave per SIMD more than the sharing, 407 vs 385 TF/s on the BEATs shape)
+  constexpr int QB = (D == 64 && !BIAS) ? 2 : 1;
+  constexpr int BQ = 32 * NW * QB;  // queries per workgroup (NW waves x QB blocks of 32)
+  constexpr int ROWB = D * 2;       // bytes per K / V row in LDS (unpadded: LDS-DMA writes lane-linear)
+  constexpr int KS = D / 16;        // QK^T k-steps
+  constexpr int DB = D / 32;        // output d-blocks
+  constexpr int CPR = D / 8;        // 16-B chunks per row
+  constexpr int NCH = 64 * CPR / (64 * NW);  // LDS-DMA wave-instructions per wave per tensor (1 KiB each)
+  constexpr int RPI = 64 / CPR;        // rows per DMA instruction
+  constexpr int BUF = 2 * 64 * ROWB;   // one K tile + one V tile
+  constexpr int NBUF = D == 64 ? 3 : 2;   // ring depth: tiles are staged NBUF-1 iterations ahead (D=128: 2 x 32 KiB keeps 2 blocks/CU)
+  constexpr int AHEAD = NBUF - 1;
+  constexpr int STG = NW * QB * 32 * (D * 2 + 16);   // epilogue staging (the K/V ring is dead by then)
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF > STG ? NBUF * BUF : STG];   // ONE barrier per KV tile
+  // gated relative-position bias: per tile and q-block the 95 table entries a wave can touch (rel = key - query over
+  // 64 keys x 32 queries) are staged once into a wave-private LDS window; a score then costs one ds_read_b32 at
+  // base + immediate instead of clamp + 64-bit address + global gather
+  __shared__ float bias_win[BIAS ? NW * QB * 128 : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hh = lane >> 5;
+  // XCD-aware decode of a 1-D grid: consecutive block ids are dispatched round-robin over the 8 XCDs, each with its own L2.
+  // Block b -> work item (b % 8) * ceil(n/8)-chunk + b / 8 (bijective), work items ordered q-block fastest: all q-blocks of
+  // one (sequence, head) run on ONE XCD back to back, so its K/V (re-read by every q-block) is fetched into one L2 once.
+  const int n_blocks = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = n_blocks >> 3, r8 = n_blocks & 7;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int qblk = item % p.n_qblocks;
+  const int head = (item / p.n_qblocks) % p.n_heads, seq = item / (p.n_qblocks * p.n_heads);
+  const int row0 = p.cu[seq];
+  const int len = p.cu[seq + 1] - row0;
+  const int qb = qblk * BQ;
+  if (qb >= len) return;
+  int kvlen = len;
+  if (p.kv_lens) kvlen = min(max(p.kv_lens[seq], 1), len);
+  const int kv_end = CAUSAL ? min(kvlen, qb + BQ) : kvlen;
+  const int n_tiles = (kv_end + 63) >> 6;
+
+  int qw[QB], qpos[QB];           // first query of each of this wave's q-blocks / this lane's query in it
+  bf16x8 qf[QB][KS];              // Q fragments (B operand of S^T = K Q^T): lane (q, hh) holds Q[q][16ks + 8hh .. +7]
+  float gate[QB];
+  const float* bias_row = nullptr;
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    qw[qi] = qb + (wave * QB + qi) * 32;
+    qpos[qi] = qw[qi] + ql;
+    const int qrow = min(qpos[qi], len - 1);
+    const unsigned short* qp = p.Q + (int64_t)(row0 + qrow) * p.ldq + head * D + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = *(const bf16x8*)(qp + ks * 16);
+    gate[qi] = 0.f;
+    if (BIAS) gate[qi] = p.rel_gate[(int64_t)(row0 + qrow) * p.n_heads + head] * LOG2E;
+  }
+  if (BIAS) bias_row = p.rel_bias + (int64_t)head * (2 * p.rel_span - 1) + (p.rel_span - 1);
+
+  // ---- staging: LDS-DMA with source-side swizzle --------------------------------------------------------
+  // DMA instruction j = wave * NCH + i of a tensor covers rows RPI*j .. RPI*j + RPI-1; lane l lands in row RPI*j + l / CPR,
+  // slot l % CPR, and fetches global chunk slot ^ f(row).  Row pointers advance by one tile per iteration; only a tile that
+  // crosses the end of the sequence takes the clamped form (rows past the end are masked, the read must stay in bounds).
+  auto f_k = [](int row) { return D == 64 ? (row >> 1) & 7 : row & 15; };
+  auto f_v = [](int row) { return D == 64 ? ((row >> 1) & 1) << 2 : (row & 3) << 2; };
+  // row 0 of this (sequence, head): packed rows [cu[seq] + j][head*D ..] of the fused QKV buffer, or — when the strides are
+  // given — rows [seq][head][j][..] of a KV cache (the prefill reads back what the QKV GEMM's epilogue appended)
+  const int64_t kv_off = p.kv_seq_stride ? (int64_t)seq * p.kv_seq_stride + (int64_t)head * p.kv_head_stride : -1;
+  const unsigned short* kbase = kv_off >= 0 ? p.K + kv_off : p.K + (int64_t)row0 * p.ldk + head * D;
+  const unsigned short* vbase = kv_off >= 0 ? p.V + kv_off : p.V + (int64_t)row0 * p.ldv + head * D;
+  const unsigned short* kptr[NCH];
+  const unsigned short* vptr[NCH];
+  int srow[NCH], kch[NCH], vch[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int j = wave * NCH + i;
+    srow[i] = RPI * j + lane / CPR;
+    kch[i] = (lane % CPR) ^ f_k(srow[i]);
+    vch[i] = (lane % CPR) ^ f_v(srow[i]);
+    kptr[i] = kbase + (int64_t)srow[i] * p.ldk + kch[i] * 8;
+    vptr[i] = vbase + (int64_t)srow[i] * p.ldv + vch[i] * 8;
+  }
+  const int64_t kstep = 64 * p.ldk, vstep = 64 * p.ldv;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto stage_tile = [&](int t, int buf) {
+    const int k0 = t * 64;
+    char* k_w = lds + buf * BUF + wave * NCH * 1024;
+    char* v_w = k_w + 64 * ROWB;
+    if (k0 + 64 <= len) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(kptr[i] + (int64_t)t * kstep), (lptr_t)(k_w + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vptr[i] + (int64_t)t * vstep), (lptr_t)(v_w + i * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int64_t grow = min(k0 + srow[i], len - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(kbase + grow * p.ldk + kch[i] * 8), (lptr_t)(k_w + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vbase + grow * p.ldv + vch[i] * 8), (lptr_t)(v_w + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  constexpr bool MFMA_ROWSUM = true;
+  bf16x8 ones8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones8[e] = (__bf16)1.0f;
+  f32x16 o_acc[QB][DB];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    m_run[qi] = NEG_BIG;
+    l_run[qi] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[qi][d][r] = 0.f;
+  }
+
+  // K fragment reads: row kb*32 + ql, logical chunk 2*ks + hh -> physical chunk ^ f_k(row) (f_k(row + 32) = f_k(row))
+  int k_off[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_off[ks] = ql * ROWB + (((2 * ks + hh) ^ f_k(ql)) << 4);
+  // transposed V reads: lane i of a 16-lane group reads row (i>>2) [+4*hh, +8 for the second read], logical chunk
+  // 4*d + 2*((lane>>4)&1) + ((lane&3)>>1), half (lane&1); the rows' f_v depends only on (i>>2)
+  int tr_off[DB];
+  {
+    const int q = (lane & 15) >> 2;
+    const int c2 = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+      tr_off[d] = (4 * hh + q) * ROWB + (((4 * d + c2) ^ f_v(q)) << 4) + (lane & 1) * 8;
+  }
+
+  // counted waits: the AHEAD-1 youngest tiles (2*NCH LDS-DMA instructions each) stay in flight across the barrier
+  auto wait_oldest_tile = [&]() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * 2 * NCH) : "memory");
+  };
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a) stage_tile(min(a, n_tiles - 1), a);
+  wait_oldest_tile();
+  __syncthreads();
+  int cur = 0;            // ring slot of tile t
+
+  for (int t = 0; t < n_tiles; ++t) {
+    // unconditional (the last iteration stages its own tile again, into the idle buffer): a conditional issue makes hipcc's
+    // waitcnt pass merge the two paths pessimistically
+    int nxt = cur + AHEAD;
+    if (nxt >= NBUF) nxt -= NBUF;
+    stage_tile(min(t + AHEAD, n_tiles - 1), nxt);   // that slot held tile t-1: last read in iteration t-1 (barrier passed)
+    const int k0 = t * 64;
+    const char* k_lds = lds + cur * BUF;
+    const char* v_lds = k_lds + 64 * ROWB;
+    // wave-uniform: which of this wave's q-blocks see a key of this tile?
+    bool active[QB];
+    bool any_active = false;
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+      active[qi] = !CAUSAL || (k0 <= qw[qi] + 31);
+      any_active |= active[qi];
+    }
+    if (any_active) {
+      // ---- S^T = K Q^T: every K fragment is read once and feeds all q-blocks --------------------------------
+      f32x16 s_acc[QB][2];
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_acc[qi][kb][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const char* kp = k_lds + kb * 32 * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(kp + k_off[ks]);
+#pragma unroll
+          for (int qi = 0; qi < QB; ++qi)
+            if (active[qi]) s_acc[qi][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][ks], s_acc[qi][kb], 0, 0, 0);
+        }
+      }
+      // ---- scores -> base-2 logits, bias, mask, online softmax; per q-block ---------------------------------------
+      bf16x8 pf[QB][2][2];
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi) {
+        if (!active[qi]) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) pf[qi][kb][h2][e] = (__bf16)0.f;
+          continue;
+        }
+        // need_mask is wave-uniform: interior tiles take the branch-free fast path (raw v_exp_f32, one FMA per score)
+        const bool need_mask = __builtin_amdgcn_readfirstlane((int)((k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw[qi]))));
+        float psum = 0.f, alpha;
+        if (!BIAS && !need_mask) {
+          float tmax = max32_raw(s_acc[qi][0], s_acc[qi][1]);
+          tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;   // scale > 0: max commutes with the scaling
+          const float m_new = max2_raw(m_run[qi], tmax);
+          alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+          m_run[qi] = m_new;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[qi][kb][r], p.scale_log2e, -m_new));
+              if (!MFMA_ROWSUM) psum += e;
+              pf[qi][kb][r >> 3][r & 7] = (__bf16)e;
+            }
+        } else {
+          float tmax;
+          const float* win = nullptr;
+          if (BIAS) {
+            float* w = bias_win + (wave * QB + qi) * 128;
+            const int base_rel = k0 - qw[qi] - 31;          // window index i <-> rel = base_rel + i, i in [0, 95)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int rel = max(-(p.rel_span - 1), min(p.rel_span - 1, base_rel + lane + 64 * i));
+              w[lane + 64 * i] = bias_row[rel];
+            }
+            __builtin_amdgcn_wave_barrier();                 // same wave, in-order LDS queue: the reads below see the writes
+            win = w + (4 * hh - ql + 31);
+          }
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              float v = s_acc[qi][kb][r] * p.scale_log2e;
+              if (BIAS) v = fmaf(gate[qi], win[kb * 32 + (r & 3) + 8 * (r >> 2)], v);
+              if (need_mask) {
+                const bool ok = (key < kvlen) && (!CAUSAL || key <= qpos[qi]);
+                v = ok ? v : NEG_BIG;
+              }
+              s_acc[qi][kb][r] = v;
+            }
+          }
+          tmax = max32_raw(s_acc[qi][0], s_acc[qi][1]);
+          tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64));
+          const float m_new = max2_raw(m_run[qi], tmax);
+          alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+          m_run[qi] = m_new;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float e = __builtin_amdgcn_exp2f(s_acc[qi][kb][r] - m_new);
+              if (need_mask) e = (s_acc[qi][kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
+              if (!MFMA_ROWSUM) psum += e;
+              pf[qi][kb][r >> 3][r & 7] = (__bf16)e;
+            }
+          }
+        }
+        if (MFMA_ROWSUM) {
+          // row sums on the matrix pipe: ones^T P^T sums the bf16-rounded probabilities over all 64 keys of the tile (every
+          // output row holds the same sums, so any accumulator register of this lane is the sum for ITS query): 4 MFMAs
+          // instead of 32 dependent v_add_f32 on the issue-bound vector port, and numerator and denominator of the softmax
+          // now see the same (rounded) weights
+          f32x16 ls;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ls[r] = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[qi][kb][s2], ls, 0, 0, 0);
+          psum = ls[0];
+        }
+        l_run[qi] = l_run[qi] * alpha + psum;
+        // the running maximum settles after the first tiles: skip the rescale when no query of the wave moved (x * 1.0f is exact)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+          for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[qi][d][r] *= alpha;
+        }
+      }
+      // ---- O^T += V^T P^T: every transposed V fragment is read once and feeds all q-blocks ----------------------------
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const char* vp = v_lds + (kb * 32 + 16 * s) * ROWB + tr_off[d];
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * ROWB));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+              if (active[qi]) o_acc[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][kb][s], o_acc[qi][d], 0, 0, 0);
+          }
+        }
+      }
+    }
+    wait_oldest_tile();   // this wave's share of tile t+1 has landed
+    __syncthreads();
+    cur = cur + 1 == NBUF ? 0 : cur + 1;
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l -------------------------------------------------------------
+  // A lane owns one query ROW, so direct stores are 8-B pieces at a row stride: every store instruction touches 64 cache
+  // lines.  The K/V ring is dead after the loop's last barrier: each wave transposes its rows through a private LDS region
+  // and stores whole head-rows (D * 2 bytes = one or two full lines), 16 B per lane.
+  float inv[QB];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    const float l_tot = MFMA_ROWSUM ? l_run[qi] : l_run[qi] + __shfl_xor(l_run[qi], 32, 64);   // the MFMA sum covers both halves' keys
+    inv[qi] = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  }
+  const bool rows16 = (((uintptr_t)p.O | (uintptr_t)(p.ldo * 2)) & 15) == 0;
+  if (rows16) {
+    constexpr int PITCH = D * 2 + 16;
+    constexpr int LPR = D * 2 / 16, RPI = 64 / LPR;     // lanes per row, rows per store instruction
+    char* stg = lds + wave * (QB * 32 * PITCH);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          *(u32x2*)(stg + (qi * 32 + ql) * PITCH + d0 * 2) =
+              u32x2{pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                    pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+        }
+    __builtin_amdgcn_wave_barrier();                    // same wave, in-order LDS queue
+#pragma unroll
+    for (int it = 0; it < QB * 32 / RPI; ++it) {
+      const int row = it * RPI + lane / LPR, cc = lane % LPR;
+      const int q = qw[row >> 5] + (row & 31);
+      const u32x4 v = *(const u32x4*)(stg + row * PITCH + cc * 16);
+      if (q < len) *(u32x4*)(p.O + (int64_t)(row0 + q) * p.ldo + head * D + cc * 8) = v;
+    }
+    return;
+  }
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    if (qpos[qi] < len) {
+      unsigned short* op = p.O + (int64_t)(row0 + qpos[qi]) * p.ldo + head * D;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          u32x2 pk = {pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                      pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+          *(u32x2*)(op + d0) = pk;
+        }
+      }
+    }
+  }
+}
+
+
+// ======================================================================================================================
+// D = 64, non-causal, no bias (the Whisper / Qwen2-Audio encoder shape): software-pipelined form.
+//
+// At D = 64 a 32-query x 64-key score tile costs 16 MFMAs (512 matrix-pipe cycles) but ~110 vector instructions + 32
+// v_exp_f32 (~700 issue cycles), and in the kernel above hipcc keeps the two in separate basic blocks: QK^T, then softmax,
+// then PV, each waiting for the one before — the matrix pipe idles under the softmax and the vector port idles under the
+// MFMAs (measured: issue port 94 % busy, matrix pipe 32 %).  Here the loop is cut into HALF-tiles (32 keys) and rotated so
+// that ONE straight-line basic block carries three independent streams:
+//        X(u+1)  S^T of the next half-tile          8 MFMAs  (4 K fragments, shared by the wave's two query blocks)
+//        Z(u-1)  O^T += V^T P^T of the previous one 8 MFMAs  (4 transposed V fragments, shared likewise)
+//        Y(u)    online softmax of the current one  ~110 VALU + 32 exp
+// so the scheduler can fill the MFMA shadows with the softmax of another half-tile.  The rescale of O by exp2(m_old - m_new)
+// is deferred to the END of the iteration (it must follow Z(u-1), which still adds P at the old scale, and precede Z(u)) and
+// sits behind a wave-uniform branch there, so the body stays one block.  Online softmax at 32-key granularity: the running
+// maximum is updated twice per tile, everything else is as above (same rounding points: bf16 P, f32 sums).
+// LDS: K ring and V ring of 3 tiles each (48 KiB): during tile period T the loop reads K(T), K(T+1), V(T-1), V(T) and
+// stages K(T+2), V(T+1); one vmcnt(0) + barrier per tile.  A trailing partial tile (kvlen % 64) is handled unpipelined
+// with masks after the pipeline has drained.
+// ======================================================================================================================
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn64_pipe_kernel(AttnParams p) {
+  constexpr int D = 64, QB = 2, BQ = 32 * NW * QB, ROWB = 128, KS = 4, DB = 2, CPR = 8;
+  constexpr int NCH = 64 * CPR / (64 * NW);   // LDS-DMA wave-instructions per wave per tensor tile (1 KiB each)
+  constexpr int RPI = 8;                      // rows per DMA instruction
+  constexpr int TILE = 64 * ROWB;             // bytes of one K (or V) tile
+  constexpr int NBUF = 3;
+  constexpr int STG = NW * QB * 32 * (D * 2 + 16);
+  constexpr int RING = 2 * NBUF * TILE;       // K ring then V ring
+  __shared__ __attribute__((aligned(16))) char lds[RING > STG ? RING : STG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int n_blocks = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = n_blocks >> 3, r8 = n_blocks & 7;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int qblk = item % p.n_qblocks;
+  const int head = (item / p.n_qblocks) % p.n_heads, seq = item / (p.n_qblocks * p.n_heads);
+  const int row0 = p.cu[seq];
+  const int len = p.cu[seq + 1] - row0;
+  const int qb = qblk * BQ;
+  if (qb >= len) return;
+  int kvlen = len;
+  if (p.kv_lens) kvlen = min(max(p.kv_lens[seq], 1), len);
+  const int n_tiles = (kvlen + 63) >> 6;
+  const int n_full = kvlen >> 6;              // tiles whose 64 keys are all valid: the pipelined part
+
+  int qw[QB], qpos[QB];
+  bf16x8 qf[QB][KS];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    qw[qi] = qb + (wave * QB + qi) * 32;
+    qpos[qi] = qw[qi] + ql;
+    const int qrow = min(qpos[qi], len - 1);
+    const unsigned short* qp = p.Q + (int64_t)(row0 + qrow) * p.ldq + head * D + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  // ---- staging (LDS-DMA, source-side swizzle; same images as attn_fwd_kernel<64>) ----------------------------------
+  auto f_k = [](int row) { return (row >> 1) & 7; };
+  auto f_v = [](int row) { return ((row >> 1) & 1) << 2; };
+  const int64_t kv_off = p.kv_seq_stride ? (int64_t)seq * p.kv_seq_stride + (int64_t)head * p.kv_head_stride : -1;
+  const unsigned short* kbase = kv_off >= 0 ? p.K + kv_off : p.K + (int64_t)row0 * p.ldk + head * D;
+  const unsigned short* vbase = kv_off >= 0 ? p.V + kv_off : p.V + (int64_t)row0 * p.ldv + head * D;
+  int srow[NCH], kch[NCH], vch[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int j = wave * NCH + i;
+    srow[i] = RPI * j + lane / CPR;
+    kch[i] = (lane % CPR) ^ f_k(srow[i]);
+    vch[i] = (lane % CPR) ^ f_v(srow[i]);
+  }
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  char* const k_ring = lds;
+  char* const v_ring = lds + NBUF * TILE;
+  // rows past the end of the sequence are clamped (they are masked or never read; the read itself must stay in bounds)
+  auto stage_k = [&](int t) {
+    t = min(t, n_tiles - 1);
+    char* w = k_ring + (t % NBUF) * TILE + wave * NCH * 1024;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int64_t grow = min(t * 64 + srow[i], len - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(kbase + grow * p.ldk + kch[i] * 8), (lptr_t)(w + i * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_v = [&](int t) {
+    t = min(t, n_tiles - 1);
+    char* w = v_ring + (t % NBUF) * TILE + wave * NCH * 1024;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int64_t grow = min(t * 64 + srow[i], len - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vbase + grow * p.ldv + vch[i] * 8), (lptr_t)(w + i * 1024), 16, 0, 0);
+    }
+  };
+
+  int k_off[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_off[ks] = ql * ROWB + (((2 * ks + hh) ^ f_k(ql)) << 4);
+  int tr_off[DB];
+  {
+    const int q = (lane & 15) >> 2;
+    const int c2 = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) tr_off[d] = (4 * hh + q) * ROWB + (((4 * d + c2) ^ f_v(q)) << 4) + (lane & 1) * 8;
+  }
+
+  f32x16 o_acc[QB][DB];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    m_run[qi] = NEG_BIG;
+    l_run[qi] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[qi][d][r] = 0.f;
+  }
+  const float c = p.scale_log2e;
+
+  // X: S^T of tile t (64 keys) for ONE query block
+  auto X = [&](int qi, int t, f32x16 (&s)[2]) {
+    const char* kp0 = k_ring + (t % NBUF) * TILE;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kp0 + kb * 32 * ROWB + k_off[ks]);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][ks], s[kb], 0, 0, 0);
+      }
+    }
+  };
+  // Z: O^T += V^T P^T of tile t for ONE query block
+  auto Z = [&](int qi, int t, const bf16x8 (&pf)[2][2]) {
+    const char* vp0 = v_ring + (t % NBUF) * TILE;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const char* vp = vp0 + (kb * 32 + 16 * s2) * ROWB + tr_off[d];
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * ROWB));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          o_acc[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], o_acc[qi][d], 0, 0, 0);
+        }
+  };
+  // Y: online softmax of one full tile for ONE query block: s -> bf16 P, running max / sum; returns the deferred O rescale factor
+  auto Y = [&](int qi, const f32x16 (&s)[2], bf16x8 (&pf)[2][2]) -> float {
+    float tmax = xhalf_max(max32_raw(s[0], s[1])) * c;
+    const float m_new = max2_raw(m_run[qi], tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+    m_run[qi] = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -m_new));
+        psum += e;
+        pf[kb][r >> 3][r & 7] = (__bf16)e;
+      }
+    l_run[qi] = l_run[qi] * alpha + psum;
+    return alpha;
+  };
+  auto rescale = [&](int qi, float alpha) {
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[qi][d][r] *= alpha;
+    }
+  };
+  auto period_end = [&](int T) {   // end of tile period T: everything staged so far has landed; next period's staging goes out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage_v(T + 2);
+    stage_k(T + 3);
+  };
+
+  // prologue: K(0), K(1), V(0) -> barrier -> (period 0's staging) K(2), V(1)
+  stage_k(0);
+  stage_v(0);
+  stage_k(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  stage_v(1);
+  stage_k(2);
+
+  if (n_full > 0) {
+    // The wave's two query blocks run half a tile period apart, so that the softmax of one always has MFMAs of the other
+    // to hide under (and vice versa):
+    //    block 1:  Z1(t-1), X1(t)   ||  Y0(t)        block 2:  Z0(t), X0(t+1)   ||  Y1(t)
+    // Invariant at the top of period t: s0 = S^T(block 0, tile t) is in flight or done, p1 = P(block 1, tile t-1).
+    // The deferred rescale of O_i sits behind a wave-uniform branch at the end of the block that computed alpha_i: it follows
+    // Z_i(t-1) and precedes Z_i(t).
+    f32x16 s0[2], s1[2];
+    bf16x8 p0[2][2], p1[2][2];
+    // the P registers feed MFMAs behind the rescale branch: without a use in this block LLVM's machine-sink pass moves the
+    // 32 exp + 16 cvt below the branch and the softmax no longer overlaps this block's MFMAs
+    auto pin = [&](bf16x8 (&pf)[2][2]) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) asm volatile("" : "+v"(pf[kb][h2]));
+    };
+    // hipcc schedules each block as "all MFMAs (with their LDS reads), then all of the softmax": in-order issue then blocks
+    // on the dependent MFMA chains for ~500 cycles before the first vector instruction goes out.  The group barriers below
+    // prescribe the interleave instead: per MFMA its LDS reads and a slice of the softmax (~9 vector instructions).
+    auto interleave16 = [&]() {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);   // VALU
+      }
+    };
+    auto interleave8 = [&]() {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
+      }
+    };
+    auto period = [&](const bool first, const bool last, int t) {
+      if (!first) Z(1, t - 1, p1);
+      X(1, t, s1);
+      const float a0 = Y(0, s0, p0);
+      pin(p0);
+      if (first) interleave8(); else interleave16();
+      rescale(0, a0);
+      Z(0, t, p0);
+      if (!last) X(0, t + 1, s0);
+      const float a1 = Y(1, s1, p1);
+      pin(p1);
+      if (last) interleave8(); else interleave16();
+      rescale(1, a1);
+      if (last) Z(1, t, p1);
+      period_end(t);
+    };
+    X(0, 0, s0);
+    if (n_full == 1) {
+      period(true, true, 0);
+    } else {
+      period(true, false, 0);
+      for (int t = 1; t + 1 < n_full; ++t) period(false, false, t);
+      period(false, true, n_full - 1);
+    }
+  }
+  if (n_full < n_tiles) {
+    // ---- trailing partial tile (index n_full), unpipelined, keys >= kvlen masked ---------------------------------------
+    const int t = n_full, k0 = t * 64;
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+      f32x16 s[2];
+      bf16x8 pf[2][2];
+      X(qi, t, s);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          s[kb][r] = key < kvlen ? s[kb][r] * c : NEG_BIG;
+        }
+      const float tmax = xhalf_max(max32_raw(s[0], s[1]));
+      const float m_new = max2_raw(m_run[qi], tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+      m_run[qi] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+          e = (s[kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
+          psum += e;
+          pf[kb][r >> 3][r & 7] = (__bf16)e;
+        }
+      l_run[qi] = l_run[qi] * alpha + psum;
+      rescale(qi, alpha);
+      Z(qi, t, pf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();     // the ring is dead from here on (epilogue staging re-uses it)
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l, whole rows through a wave-private LDS region ----------------------------------
+  float inv[QB];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+    inv[qi] = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  }
+  const bool rows16 = (((uintptr_t)p.O | (uintptr_t)(p.ldo * 2)) & 15) == 0;
+  if (rows16) {
+    constexpr int PITCH = D * 2 + 16;
+    constexpr int LPR = D * 2 / 16, RPS = 64 / LPR;     // lanes per row, rows per store instruction
+    char* stg = lds + wave * (QB * 32 * PITCH);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          *(u32x2*)(stg + (qi * 32 + ql) * PITCH + d0 * 2) =
+              u32x2{pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                    pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < QB * 32 / RPS; ++it) {
+      const int row = it * RPS + lane / LPR, cc = lane % LPR;
+      const int q = qw[row >> 5] + (row & 31);
+      const u32x4 v = *(const u32x4*)(stg + row * PITCH + cc * 16);
+      if (q < len) *(u32x4*)(p.O + (int64_t)(row0 + q) * p.ldo + head * D + cc * 8) = v;
+    }
+    return;
+  }
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    if (qpos[qi] < len) {
+      unsigned short* op = p.O + (int64_t)(row0 + qpos[qi]) * p.ldo + head * D;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          *(u32x2*)(op + d0) = u32x2{pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                                     pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+        }
+    }
+  }
+}
+
+template <int D, int NW>
+int launch_attn_nw(const AttnParams& p, const icl_attn_args* a, hipStream_t stream) {
+  const bool bias = a->rel_bias != nullptr;
+  const int bq = 32 * NW * ((D == 64 && !bias) ? 2 : 1);   // queries per workgroup (NW waves x QB blocks of 32 in the kernel)
+  dim3 grid(((a->max_seqlen + bq - 1) / bq) * a->n_heads * a->n_seqs, 1, 1);
+  if (a->causal) {
+    if (bias)
+      hipLaunchKernelGGL((attn_fwd_kernel<D, true, true, NW>), grid, dim3(64 * NW), 0, stream, p);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<D, true, false, NW>), grid, dim3(64 * NW), 0, stream, p);
+  } else {
+    if (bias)
+      hipLaunchKernelGGL((attn_fwd_kernel<D, false, true, NW>), grid, dim3(64 * NW), 0, stream, p);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<D, false, false, NW>), grid, dim3(64 * NW), 0, stream, p);
+  }
+  ICL_CHECK_LAUNCH("icl_attn_fwd_bf16");
+  return ICL_OK;
+}
+
+// waves per workgroup: every K/V tile is staged once per workgroup, so 8 waves halve the LDS-DMA instructions per wave and
+// tile (the staging issue cost was the largest single ablation of this loop); long non-causal sequences take the 8-wave
+// form, short / causal ones keep 4 waves (more, smaller workgroups balance the causal triangle better)
+inline int attn_waves(const icl_attn_args* a) {
+  static const int forced = [] { const char* e = getenv("ICL_ATTN_NW"); return e ? atoi(e) : 0; }();
+  if (forced == 4 || forced == 8) return forced;
+  return (a->head_dim == 64 && !a->causal && !a->rel_bias && a->max_seqlen >= 1024) ? 8 : 4;
+}
+
+}  // namespace
+
+extern "C" int icl_attn_fwd_bf16(const icl_attn_args* a, void* stream) {
+  ICL_CHECK_ARG(a != nullptr, "icl_attn_fwd_bf16: args is NULL");
+  ICL_CHECK_ARG(a->Q && a->K && a->V && a->O && a->cu_seqlens, "icl_attn_fwd_bf16: NULL pointer");
+  ICL_CHECK_ARG(a->head_dim == 64 || a->head_dim == 128, "icl_attn_fwd_bf16: head_dim=%d (only 64 and 128)", a->head_dim);
+  ICL_CHECK_ARG(a->n_seqs > 0 && a->n_seqs <= 65535 && a->n_heads > 0 && a->n_heads <= 65535 && a->max_seqlen > 0,
+                "icl_attn_fwd_bf16: bad n_seqs/n_heads/max_seqlen");
+  ICL_CHECK_ARG(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0,
+                "icl_attn_fwd_bf16: leading dimensions must be multiples of 8 (ldo: 4)");
+  ICL_CHECK_ARG(((uintptr_t)a->Q & 15) == 0 && ((uintptr_t)a->K & 15) == 0 && ((uintptr_t)a->V & 15) == 0 &&
+                    ((uintptr_t)a->O & 7) == 0,
+                "icl_attn_fwd_bf16: Q/K/V must be 16-byte and O 8-byte aligned");
+  ICL_CHECK_ARG((a->rel_bias == nullptr) == (a->rel_gate == nullptr), "icl_attn_fwd_bf16: rel_bias and rel_gate go together");
+  if (a->rel_bias) ICL_CHECK_ARG(a->rel_span >= 1, "icl_attn_fwd_bf16: rel_span must be >= 1");
+  AttnParams p;
+  p.Q = (const unsigned short*)a->Q;
+  p.K = (const unsigned short*)a->K;
+  p.V = (const unsigned short*)a->V;
+  p.O = (unsigned short*)a->O;
+  p.cu = a->cu_seqlens;
+  p.kv_lens = a->kv_lens;
+  p.rel_bias = a->rel_bias;
+  p.rel_gate = a->rel_gate;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+  ICL_CHECK_ARG((a->kv_seq_stride == 0) == (a->kv_head_stride == 0) && a->kv_seq_stride >= 0 && a->kv_head_stride >= 0 &&
+                    a->kv_seq_stride % 8 == 0 && a->kv_head_stride % 8 == 0,
+                "icl_attn_fwd_bf16: kv_seq_stride / kv_head_stride must both be 0 or both positive multiples of 8");
+  p.kv_seq_stride = a->kv_seq_stride; p.kv_head_stride = a->kv_head_stride;
+  p.n_heads = a->n_heads;
+  p.rel_span = a->rel_span;
+  const int nw = attn_waves(a);
+  const int bq = 32 * nw * ((a->head_dim == 64 && !a->rel_bias) ? 2 : 1);
+  p.n_qblocks = (a->max_seqlen + bq - 1) / bq;
+  p.scale_log2e = a->scale * LOG2E;
+  static const int pipe = [] { const char* e = getenv("ICL_ATTN_PIPE"); return e ? atoi(e) : 1; }();
+  if (pipe && a->head_dim == 64 && !a->causal && !a->rel_bias) {
+    dim3 grid(p.n_qblocks * a->n_heads * a->n_seqs, 1, 1);
+    if (nw == 8)
+      hipLaunchKernelGGL((attn64_pipe_kernel<8>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL((attn64_pipe_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    ICL_CHECK_LAUNCH("icl_attn_fwd_bf16");
+    return ICL_OK;
+  }
+  if (a->head_dim == 64)
+    return nw == 8 ? launch_attn_nw<64, 8>(p, a, (hipStream_t)stream) : launch_attn_nw<64, 4>(p, a, (hipStream_t)stream);
+  return nw == 8 ? launch_attn_nw<128, 8>(p, a, (hipStream_t)stream) : launch_attn_nw<128, 4>(p, a, (hipStream_t)stream);
+}
