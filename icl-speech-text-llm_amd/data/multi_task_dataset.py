@@ -15,6 +15,8 @@ log-mel (the reference's ``torch.tensor(audio)`` keeps float64 — SURVEY.md §8
 """
 from __future__ import annotations
 
+from ..utils.audio_io import decode_audio
+
 import logging
 import random
 import time
@@ -42,7 +44,13 @@ def convert_ner_to_dict(text: str, ner_data: Dict) -> Dict[str, List[str]]:
 
 
 def _wave(x) -> Optional[np.ndarray]:
-    return None if x is None else np.asarray(x, dtype=np.float32).reshape(-1)
+    """float32 waveform of an ``["array"]`` value (the reference's access path) or of a whole audio cell."""
+    return decode_audio(x)
+
+
+def _cell_wave(cell) -> Optional[np.ndarray]:
+    """An audio CELL: decoded ``{"array", "sampling_rate"}`` or ``Audio(decode=False)``'s ``{"bytes", "path"}`` (utils/audio_io.py)."""
+    return decode_audio(cell)
 
 
 class BaseMultiTaskDataset(Dataset):
@@ -142,18 +150,18 @@ class BaseMultiTaskDataset(Dataset):
             if "index" in ex:
                 audio = self._get_audio_by_index(ex["index"])
                 if audio is not None:
-                    out.append(_wave(audio["array"]))
+                    out.append(_cell_wave(audio))
         return out or None
 
     def _get_main_audio(self, item):
         if "speech" in self.input_mode and "audio" in item:
-            return _wave(item["audio"]["array"])
+            return _cell_wave(item["audio"])
         return None
 
     @staticmethod
     def _get_audio_by_key(item, key):
         if key in item and item[key] is not None:
-            return _wave(item[key]["array"])
+            return _cell_wave(item[key])
         return None
 
     # ---- items -------------------------------------------------------------------------------------------------
@@ -175,8 +183,8 @@ class BaseMultiTaskDataset(Dataset):
                 examples.append({"text": ex[cfg.text_key],
                                  "label": self._format_label(ex[cfg.completion_key], is_example=False,
                                                              current_mapping=cfg.label_mapping, text=ex[cfg.text_key])})
-                if self.fewshot_mode == "speech" and "audio" in ex and ex["audio"]["array"] is not None:
-                    examples_audio.append(_wave(ex["audio"]["array"]))
+                if self.fewshot_mode == "speech" and ex.get("audio") is not None and _cell_wave(ex["audio"]) is not None:
+                    examples_audio.append(_cell_wave(ex["audio"]))
         else:
             selected = self._select_examples(item.get("few_shot_examples", []))
             examples = [{"text": ex["text"],

@@ -27,7 +27,8 @@ def load_dataset(dataset_type: DatasetType, split="train", use_cache: bool = Tru
         raise FileNotFoundError(f"Dataset file not found: {path}")
     from datasets import load_from_disk
     t0 = time.time()
-    data = load_from_disk(path)
+    from .audio_io import undecoded_audio_columns
+    data = undecoded_audio_columns(load_from_disk(path))     # Audio columns still decode lazily where a backend exists
     logger.info("Loaded %d examples from %s %s in %.2fs", len(data), dataset_type, split, time.time() - t0)
     if use_cache:
         _DATASET_CACHE[key] = data

@@ -349,3 +349,77 @@ def test_workspace_capacity_is_bounded_and_tracks_generation():
     p = kv1.k.data_ptr()
     kv2 = KVCache(_C, 2, 64, ws)
     assert kv2.k.data_ptr() == p and kv2.k.shape == (2, 2, 4, 64, 8)     # one K allocation, re-viewed per batch shape
+
+
+def test_audio_cells_decode_without_a_datasets_backend(tmp_path):
+    """f2 / f3 (real on-disk formats): an HF ``Audio``-typed column (``data/multi_task_dataset.py:135-158`` reads
+    ``item["audio"]["array"]`` and relies on the datasets decoder) is read here even when no decoder backend is installed:
+    the column is cast to decode=False and the stored RIFF/WAVE bytes are parsed by utils/audio_io.py — PCM16, IEEE float, stereo
+    (averaged), 8 kHz (resampled to 16 kHz); decoded cells and bare lists pass through; a FLAC payload raises a clear error."""
+    import io, struct, wave
+    import numpy as np
+    from icl_speech_text_llm_amd.utils.audio_io import decode_audio, undecoded_audio_columns, audio_backend_available
+    rng = np.random.default_rng(3)
+    x = np.clip(rng.normal(0, 0.1, 4000), -1, 1).astype(np.float32)
+
+    def pcm16(sig, sr=16000, ch=1):
+        b = io.BytesIO()
+        with wave.open(b, "wb") as w:
+            w.setnchannels(ch); w.setsampwidth(2); w.setframerate(sr)
+            w.writeframes((np.round(sig * 32767).astype("<i2")).tobytes())
+        return b.getvalue()
+
+    got = decode_audio({"bytes": pcm16(x), "path": None})
+    assert got.dtype == np.float32 and got.shape == x.shape and float(np.abs(got - x).max()) <= 1.0 / 32767 + 1e-7
+    stereo = np.stack([x, -x * 0.5], 1).reshape(-1)
+    got2 = decode_audio({"bytes": pcm16(stereo, ch=2), "path": None})
+    assert got2.shape == x.shape and float(np.abs(got2 - 0.25 * x).max()) < 1e-4
+    f32 = b"RIFF" + struct.pack("<I", 36 + 4 * x.size) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 1, 16000, 64000, 4, 32) + \
+        b"data" + struct.pack("<I", 4 * x.size) + x.astype("<f4").tobytes()
+    assert np.array_equal(decode_audio({"bytes": f32}), x)
+    low = decode_audio({"array": x[:2000].tolist(), "sampling_rate": 8000})
+    assert low.shape == (4000,)                                           # 8 kHz -> 16 kHz
+    assert np.array_equal(decode_audio({"array": x, "sampling_rate": 16000}), x) and np.array_equal(decode_audio(x.tolist()), x)
+    assert decode_audio(None) is None
+    with pytest.raises(ValueError, match="FLAC"):
+        decode_audio({"bytes": b"fLaC" + b"\0" * 64})
+    # through an HF dataset folder with an Audio-typed column and the item pipeline
+    import datasets
+    from icl_speech_text_llm_amd.data import task_configs as tc
+    from icl_speech_text_llm_amd.data.dataset_factory import DatasetFactory
+    from icl_speech_text_llm_amd.data.model_processors import SalmonProcessor
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_synthetic_hf_datasets
+    from icl_speech_text_llm_amd.utils.data_utils import clear_dataset_cache, load_dataset
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    try:
+        write_synthetic_hf_datasets(str(tmp_path), [tc.DatasetType.VOXCELEB], n_items=3, n_lookup=8, n_fewshot=5,
+                                    audio_seconds=(0.3, 0.6), splits=("test",))
+        clear_dataset_cache()
+        cfg = tc.get_dataset_config(tc.DatasetType.VOXCELEB)
+        path = cfg.get_path(tc.DatasetSplit.TEST)
+        plain = datasets.load_from_disk(path)
+        want = [np.asarray(r["audio"]["array"], dtype=np.float32) for r in plain]
+        typed = plain.map(lambda r: {"audio": {"bytes": pcm16(np.asarray(r["audio"]["array"], dtype=np.float32)), "path": None}})
+        typed = typed.cast_column("audio", datasets.Audio(sampling_rate=16000, decode=False))
+        typed = typed.cast_column("audio", datasets.Audio(sampling_rate=16000))          # what a real folder declares
+        import shutil
+        typed.save_to_disk(path + "_typed")                 # a dataset cannot overwrite the folder it was loaded from
+        del plain, typed
+        shutil.rmtree(path)
+        os.rename(path + "_typed", path)
+        clear_dataset_cache()
+        rows = load_dataset(tc.DatasetType.VOXCELEB, split="test")
+        if not audio_backend_available():
+            assert rows.features["audio"].decode is False
+        ds = DatasetFactory.create_dataset(dataset_type=[tc.DatasetType.VOXCELEB], dataset={tc.DatasetType.VOXCELEB: rows},
+                                           processor=SalmonProcessor(ByteTokenizer(260)), is_training=False, input_mode="speech_only",
+                                           fewshot_mode="text", num_examples=2, random_examples=False)
+        by_len = {w.shape[0]: w for w in want}              # the multi-task wrapper orders items its own way: match by length
+        assert len(by_len) == len(want) == len(ds)
+        for i in range(len(ds)):
+            wav = np.asarray(ds[i]["raw_wav"], dtype=np.float32).reshape(-1)
+            ref = by_len[wav.shape[0]]
+            assert float(np.abs(wav - ref).max()) <= 1.0 / 32767 + 1e-6
+    finally:
+        tc.set_dataset_root(None)
+        clear_dataset_cache()
