@@ -95,8 +95,10 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true", help="run the decode loop eagerly (rocprofv3 --pmc crashes on HIP-graph capture)")
     ap.add_argument("--tiny", action="store_true", help="miniature model (smoke only; not a valid bench number)")
     ap.add_argument("--through-plugin", action="store_true",
-                    help="also time the path through the reference-compatible plugin: ModelFactory -> SalmonProcessor / DataLoader "
-                         "-> generate_output (H2D, tokenisation, batch_decode inside the timed region; SURVEY.md §8d)")
+                    help="(default at N=1 on the headline workload) also time the path through the reference-compatible plugin: "
+                         "ModelFactory -> SalmonProcessor / DataLoader -> generate_output (H2D, tokenisation, batch_decode inside "
+                         "the timed region; SURVEY.md §8d)")
+    ap.add_argument("--no-through-plugin", action="store_true", help="skip the plugin-path leg")
     ap.add_argument("--plugin-workers", type=int, default=8)
     ap.add_argument("--plugin-batch", type=int, default=64)
     ap.add_argument("--workload", default="c2", choices=["c2", "c2s", "c4", "c5"],
@@ -653,9 +655,12 @@ def main():
             "workspace_gib": round(rt.ws.nbytes() / 2 ** 30, 2),
             "build_s": round(t_build, 1), "first_utterance_tokens": first_tokens,
         }
-        if args.through_plugin and world == 1 and args.workload == "c2":
+        if world == 1 and args.workload == "c2" and not args.no_through_plugin and (args.through_plugin or not args.tiny):
             log("through-plugin leg ...")
-            out["through_plugin"] = through_plugin(args, dev)
+            try:
+                out["through_plugin"] = through_plugin(args, dev)
+            except Exception as e:       # a reported side number must never cost the headline line
+                out["through_plugin"] = {"error": f"{type(e).__name__}: {e}"}
             log(f"through-plugin: {out['through_plugin']}")
         if want_cpu:
             threads = host_cores()
