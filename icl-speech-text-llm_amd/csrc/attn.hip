@@ -67,6 +67,13 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
   // barrier (the loop is issue-bound, not MFMA-bound); the gated-bias variant keeps one (measured: its longer per-score
   // sequence wants the third wave per SIMD more than the sharing, 407 vs 385 TF/s on the BEATs shape)
   constexpr int QB = (D == 64 && !BIAS) ? 2 : 1;
+  // D = 128 (the decoders' prefill / teacher-forced attention): P enters the PV product as a TWO-term bf16 split,
+  // P = hi + lo with hi = bf16(P), lo = bf16(P - hi) (16 mantissa bits instead of 8), at the price of a second PV MFMA.
+  // The oracle's softmax weights are f32: with one-term bf16 P this single rounding point alone put the decoder logits
+  // 3.7e-3 (relative L2) from the oracle — measured by rounding P inside the ORACLE — against the north star's 1e-3; with the
+  // split they sit at the level of the other, mirrored, rounding points.  The D = 64 encoder kernels keep one term: they
+  // meet ~1e-3 already and are vector-issue-bound, where the extra conversions would cost 15-20 %.
+  constexpr bool P2 = (D == 128);
   constexpr int BQ = 128 * QB;      // queries per workgroup
   constexpr int ROWB = D * 2;       // bytes per K / V row in LDS (unpadded: LDS-DMA writes lane-linear)
   constexpr int KS = D / 16;        // QK^T k-steps
@@ -243,6 +250,7 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
       }
       // ---- scores -> base-2 logits, bias, mask, online softmax; per q-block ---------------------------------------
       bf16x8 pf[QB][2][2];
+      bf16x8 pl[P2 ? QB : 1][2][2];      // low halves of the two-term bf16 split of P (D = 128 only)
 #pragma unroll
       for (int qi = 0; qi < QB; ++qi) {
         if (!active[qi]) {
@@ -251,7 +259,10 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-              for (int e = 0; e < 8; ++e) pf[qi][kb][h2][e] = (__bf16)0.f;
+              for (int e = 0; e < 8; ++e) {
+                pf[qi][kb][h2][e] = (__bf16)0.f;
+                if (P2) pl[qi][kb][h2][e] = (__bf16)0.f;
+              }
           continue;
         }
         // need_mask is wave-uniform: interior tiles take the branch-free fast path (raw v_exp_f32, one FMA per score)
@@ -270,6 +281,7 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
               const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[qi][kb][r], p.scale_log2e, -m_new));
               psum += e;
               pf[qi][kb][r >> 3][r & 7] = (__bf16)e;
+              if (P2) pl[qi][kb][r >> 3][r & 7] = (__bf16)(e - (float)pf[qi][kb][r >> 3][r & 7]);
             }
         } else {
           float tmax;
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
               if (need_mask) e = (s_acc[qi][kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
               psum += e;
               pf[qi][kb][r >> 3][r & 7] = (__bf16)e;
+              if (P2) pl[qi][kb][r >> 3][r & 7] = (__bf16)(e - (float)pf[qi][kb][r >> 3][r & 7]);
             }
           }
         }
@@ -339,7 +352,10 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
             const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi)
-              if (active[qi]) o_acc[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][kb][s], o_acc[qi][d], 0, 0, 0);
+              if (active[qi]) {
+                o_acc[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qi][kb][s], o_acc[qi][d], 0, 0, 0);
+                if (P2) o_acc[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pl[qi][kb][s], o_acc[qi][d], 0, 0, 0);
+              }
           }
         }
       }

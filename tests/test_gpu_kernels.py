@@ -245,6 +245,28 @@ def test_attn_fwd(B, D, H, causal, lens):
     assert _relerr(out, ref) < 1e-2
 
 
+def test_attn_fwd_d128_is_exact_up_to_the_output_rounding(B):
+    """D = 128 (decoder prefill): P enters PV as a two-term bf16 split, so the kernel's bf16 output equals the f64 softmax-attention
+    result ROUNDED to bf16 in all but a fraction of a percent of the elements (measured: 0.2 % differ, by one ulp) — the only
+    rounding left is the one the oracle applies too (attention output -> bf16)."""
+    D, H, L = 128, 2, 376
+    qkv = _rand_bf16(L, 3 * H * D, seed=31)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    out = torch.empty(L, H * D, dtype=torch.bfloat16, device=DEV)
+    cu_t = torch.tensor([0, L], dtype=torch.int32, device=DEV)
+    B.attn_fwd(q, k, v, out, cu_t, L, H, D, D ** -0.5, causal=True)
+    qs, ks, vs = (t.double().view(L, H, D).transpose(0, 1) for t in (q, k, v))
+    sc = qs @ ks.transpose(1, 2) * D ** -0.5
+    i = torch.arange(L, device=DEV)
+    sc = sc.masked_fill((i[None, :] > i[:, None])[None], float("-inf"))
+    exact = (torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(L, H * D)
+    rounded = exact.to(torch.bfloat16)
+    differ = float((out != rounded).double().mean())
+    rel = float((out.double() - rounded.double()).norm() / exact.norm())
+    print(f"attn D=128: {differ:.4f} of the elements differ from the rounded exact result, rel-L2 {rel:.2e}")
+    assert differ < 0.01 and rel < 2e-4
+
+
 @pytest.mark.parametrize("D,H,causal", [(128, 3, True), (64, 2, False)])
 def test_attn_fwd_reads_kv_from_cache_layout(B, D, H, causal):
     """K / V addressed as [seq][head][pos][D] cache rows (what the fused QKV epilogue appends) == the packed-row form, bit

@@ -146,7 +146,7 @@ def test_llama_forward_logits_and_loss(env):
         eb, ef = _rel(g, lb[0]), _rel(g, lf[0])
         print(f"llama logits[{i}] S={S}: rel err vs bf16-rounding oracle {eb:.2e}, vs fp32 oracle {ef:.2e}; "
               f"max abs {float((g.cpu() - lb[0]).abs().max()):.2e} (|logit| max {float(lb.abs().max()):.2f})")
-        assert eb < TOL_LOGITS_REL and ef < 1.2e-2   # measured: 3.7e-3 / 5.9e-3 (floor: bf16 P inside flash attention)
+        assert eb < TOL_LOGITS_REL and ef < 1.2e-2   # measured: 2.4e-3 / 5.7e-3 (two-term bf16 P in the D = 128 attention)
         shifted = torch.full((S,), -100, dtype=torch.int32)
         shifted[:-1] = labels[0, 1:].to(torch.int32)
         loss = rt.cross_entropy(g, shifted).cpu()
@@ -155,7 +155,7 @@ def test_llama_forward_logits_and_loss(env):
 
 
 # asserted bounds = ~2x the values measured on MI355X (printed by the tests)
-TOL_LOGITS_REL = 6e-3        # packed prefill / decode logits vs the bf16-rounding oracle, relative L2 per row (measured 4.1e-3)
+TOL_LOGITS_REL = 5e-3        # packed prefill / decode logits vs the bf16-rounding oracle, relative L2 per row (measured 2.4e-3 / 3.4e-3)
 
 
 def test_llama_generate_matches_oracle(env):

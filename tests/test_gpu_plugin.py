@@ -92,7 +92,7 @@ def test_forward_loss_logits_labels(model):
     ref_logits, ref_loss = llm.forward(full, labels.cpu())
     rel = float((logits.cpu() - ref_logits).norm() / ref_logits.norm())
     print(f"plugin forward logits rel {rel:.2e}")
-    assert rel < 6e-3, rel                       # measured ~3.6e-3 (floor: bf16 P inside flash attention)
+    assert rel < 3e-3, rel                       # measured 1.5e-3
     assert abs(float(loss) - float(ref_loss)) < 5e-3 * max(1.0, abs(float(ref_loss)))
 
 
@@ -207,7 +207,7 @@ def test_sqa_two_audio_batches_match_oracle(model, tmp_path):
             ref_logits, ref_loss = llm.forward(full, out["labels"].cpu())
             rel = float((out["logits"].cpu() - ref_logits).norm() / ref_logits.norm())
             print(f"sqa forward logits rel {rel:.2e}")
-            assert rel < 6e-3, rel
+            assert rel < 3e-3, rel               # measured 1.3e-3
             text = model.generate_output({k_: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k_, v in b.items()})
             assert len(text) == 1 and isinstance(text[0], str)
         b2 = _sqa_batch(model, tmp_path, "speech", 2, bs=2)       # batch of 2, two speech exemplars each: 12 audios, one chain

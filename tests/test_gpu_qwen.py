@@ -47,7 +47,7 @@ def test_audio_tower_matches_oracle(model):
     for i, n in enumerate(out_lens):
         r = _rel(feats[i, :n], ref[i, :n])
         print(f"qwen audio tower[{i}]: rel {r:.2e}")
-        assert r < 5e-3, i
+        assert r < 1.5e-3, i               # measured 5.5e-4 .. 6.9e-4
 
 
 def test_forward_and_generate_match_oracle(model):
@@ -73,7 +73,7 @@ def test_forward_and_generate_match_oracle(model):
     ref_logits, ref_loss = llm.forward(emb[None], labels)
     r = _rel(out["logits"], ref_logits)
     print(f"qwen forward logits rel {r:.2e}")
-    assert r < 6e-3
+    assert r < 4e-3                      # measured 2.0e-3
     assert abs(float(out["loss"]) - float(ref_loss)) < 5e-3 * max(1.0, abs(float(ref_loss)))
     # generation: prompt only
     gen_batch = {k: (v[:, :prompt_len] if k in ("input_ids", "attention_mask") else v) for k, v in batch.items()}
@@ -86,7 +86,7 @@ def test_forward_and_generate_match_oracle(model):
     _, first = llm.generate_greedy(emb[None, :prompt_len], 1, -1, c.pad_id, return_first_logits=True)
     e = float((res.first_logits.cpu() - first).abs().max())
     print(f"qwen first-step logits max abs {e:.2e}")
-    assert e < 1e-2
+    assert e < 5e-3                      # measured 2.1e-3
     assert res.tokens.shape == (1, 5)
 
 
