@@ -61,20 +61,19 @@ __device__ __forceinline__ float max32_raw(const f32x16& a, const f32x16& b) {
 }
 constexpr float LOG2E = 1.4426950408889634f;
 
-template <int D, bool CAUSAL, bool BIAS, bool PREC>
+template <int D, bool CAUSAL, bool BIAS>
 __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
   // 32-query blocks per wave: at D = 64 two of them share every K and V fragment read, every staged byte and every
   // barrier (the loop is issue-bound, not MFMA-bound); the gated-bias variant keeps one (measured: its longer per-score
   // sequence wants the third wave per SIMD more than the sharing, 407 vs 385 TF/s on the BEATs shape)
-  constexpr int QB = (D == 64 && !BIAS && !PREC) ? 2 : 1;
+  constexpr int QB = (D == 64 && !BIAS) ? 2 : 1;
   // D = 128 (the decoders' prefill / teacher-forced attention): P enters the PV product as a TWO-term bf16 split,
   // P = hi + lo with hi = bf16(P), lo = bf16(P - hi) (16 mantissa bits instead of 8), at the price of a second PV MFMA.
   // The oracle's softmax weights are f32: with one-term bf16 P this single rounding point alone put the decoder logits
   // 3.7e-3 (relative L2) from the oracle — measured by rounding P inside the ORACLE — against the north star's 1e-3; with the
-  // split they sit at the level of the other, mirrored, rounding points.  The D = 64 encoder kernels keep one term by default:
-  // they meet ~1e-3 already and are vector-issue-bound, where the extra conversions and MFMAs cost ~20 %; PREC (flags bit 0 of
-  // icl_attn_args, `precise=True` in the binding) selects the split there too, with one query block per wave for the registers.
-  constexpr bool P2 = (D == 128) || PREC;
+  // split they sit at the level of the other, mirrored, rounding points.  The D = 64 encoder kernels keep one term: they
+  // meet ~1e-3 already and are vector-issue-bound, where the extra conversions would cost 15-20 %.
+  constexpr bool P2 = (D == 128);
   constexpr int BQ = 128 * QB;      // queries per workgroup
   constexpr int ROWB = D * 2;       // bytes per K / V row in LDS (unpadded: LDS-DMA writes lane-linear)
   constexpr int KS = D / 16;        // QK^T k-steps
@@ -422,27 +421,19 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
 
 template <int D>
 int launch_attn(const AttnParams& p, const icl_attn_args* a, hipStream_t stream) {
-  const bool bias = a->rel_bias != nullptr;
-  const bool prec = D == 64 && !a->causal && (a->reserved & 1);
-  const int bq = (D == 64 && !bias && !prec) ? 256 : 128;   // queries per workgroup (QB in the kernel)
+  const int bq = (D == 64 && !a->rel_bias) ? 256 : 128;   // queries per workgroup (QB in the kernel)
   dim3 grid(((a->max_seqlen + bq - 1) / bq) * a->n_heads * a->n_seqs, 1, 1);
+  const bool bias = a->rel_bias != nullptr;
   if (a->causal) {
     if (bias)
-      hipLaunchKernelGGL((attn_fwd_kernel<D, true, true, false>), grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(256), 0, stream, p);
     else
-      hipLaunchKernelGGL((attn_fwd_kernel<D, true, false, false>), grid, dim3(256), 0, stream, p);
-  } else if (prec) {
-    if constexpr (D == 64) {
-      if (bias)
-        hipLaunchKernelGGL((attn_fwd_kernel<64, false, true, true>), grid, dim3(256), 0, stream, p);
-      else
-        hipLaunchKernelGGL((attn_fwd_kernel<64, false, false, true>), grid, dim3(256), 0, stream, p);
-    }
+      hipLaunchKernelGGL((attn_fwd_kernel<D, true, false>), grid, dim3(256), 0, stream, p);
   } else {
     if (bias)
-      hipLaunchKernelGGL((attn_fwd_kernel<D, false, true, false>), grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(256), 0, stream, p);
     else
-      hipLaunchKernelGGL((attn_fwd_kernel<D, false, false, false>), grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((attn_fwd_kernel<D, false, false>), grid, dim3(256), 0, stream, p);
   }
   ICL_CHECK_LAUNCH("icl_attn_fwd_bf16");
   return ICL_OK;
@@ -479,8 +470,7 @@ extern "C" int icl_attn_fwd_bf16(const icl_attn_args* a, void* stream) {
   p.kv_seq_stride = a->kv_seq_stride; p.kv_head_stride = a->kv_head_stride;
   p.n_heads = a->n_heads;
   p.rel_span = a->rel_span;
-  const bool prec = a->head_dim == 64 && !a->causal && (a->reserved & 1);
-  const int bq = (a->head_dim == 64 && !a->rel_bias && !prec) ? 256 : 128;
+  const int bq = (a->head_dim == 64 && !a->rel_bias) ? 256 : 128;
   p.n_qblocks = (a->max_seqlen + bq - 1) / bq;
   p.scale_log2e = a->scale * LOG2E;
   return a->head_dim == 64 ? launch_attn<64>(p, a, (hipStream_t)stream) : launch_attn<128>(p, a, (hipStream_t)stream);

@@ -239,10 +239,8 @@ def rope_fusable(M: int, n_heads: int, head_dim: int, K: int) -> bool:
 
 
 def attn_fwd(q, k, v, out, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: int, scale: float, *,
-             causal=False, kv_lens=None, rel_bias=None, rel_gate=None, rel_span: int = 0, kv_cache_max_len: int = 0,
-             precise: bool = False):
-    """``kv_cache_max_len`` > 0: k / v are KV-cache tensors [n_seqs, n_heads, max_len, head_dim] (read in place).
-    ``precise``: two-term bf16 split of the softmax weights also at head_dim 64 (head_dim 128 always has it)."""
+             causal=False, kv_lens=None, rel_bias=None, rel_gate=None, rel_span: int = 0, kv_cache_max_len: int = 0):
+    """``kv_cache_max_len`` > 0: k / v are KV-cache tensors [n_seqs, n_heads, max_len, head_dim] (read in place)."""
     _require_gpu(q, k, v, out, cu_seqlens, kv_lens, rel_bias, rel_gate)
     lib = load_library()
     a = AttnArgs()
@@ -250,7 +248,7 @@ def attn_fwd(q, k, v, out, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: 
     a.cu_seqlens, a.kv_lens = cu_seqlens.data_ptr(), _ptr(kv_lens)
     a.rel_bias, a.rel_gate = _ptr(rel_bias), _ptr(rel_gate)
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
-    a.reserved = 1 if precise else 0
+    a.reserved = 0
     if kv_cache_max_len > 0:
         a.ldk = a.ldv = head_dim
         a.kv_seq_stride, a.kv_head_stride = n_heads * kv_cache_max_len * head_dim, kv_cache_max_len * head_dim

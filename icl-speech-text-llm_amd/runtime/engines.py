@@ -92,8 +92,6 @@ class LogMel:
 # K2 + K3: Whisper encoder
 # ================================================================================================
 class WhisperEncoderHIP:
-    precise_attention = False     # two-term bf16 P also in the head_dim-64 attention (~20 % slower attention, ~2x closer to the oracle)
-
     def __init__(self, w: PackedWhisper):
         self.w = w
 
@@ -123,8 +121,7 @@ class WhisperEncoderHIP:
         for L in w.layers:
             B.layernorm(h, L.ln1_g, L.ln1_b, xn, 1e-5)
             B.gemm(xn, L.wqkv, qkv, bias=L.bqkv)
-            B.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, cu, T, c.n_heads, D, D ** -0.5, kv_lens=kv_lens,
-                       precise=self.precise_attention)
+            B.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, cu, T, c.n_heads, D, D ** -0.5, kv_lens=kv_lens)
             B.gemm(att, L.wo, h, bias=L.bo, residual=h)
             B.layernorm(h, L.ln2_g, L.ln2_b, xn, 1e-5)
             B.gemm(xn, L.w1, ff, bias=L.b1, gelu=True)
@@ -173,8 +170,6 @@ class QwenAudioTowerHIP:
 # K4 + K5: BEATs
 # ================================================================================================
 class BeatsHIP:
-    precise_attention = False
-
     def __init__(self, w: PackedBeats, device):
         from .audio_tables import kaldi_mel_banks
         self.w = w
@@ -250,7 +245,7 @@ class BeatsHIP:
             B.gemm(xb, L.wqkv, qkv, bias=L.bqkv)
             B.beats_gate(qkv, L.extra["grep_w"], L.extra["grep_b"], L.extra["grep_a"], gate, c.n_heads)
             B.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, cu, max(T), c.n_heads, 64, 0.125,
-                       kv_lens=valid, rel_bias=w.rel_table, rel_gate=gate, rel_span=w.rel_span, precise=self.precise_attention)
+                       kv_lens=valid, rel_bias=w.rel_table, rel_gate=gate, rel_span=w.rel_span)
             B.gemm(att, L.wo, o, bias=L.bo)
             B.layernorm(o, L.ln1_g, L.ln1_b, x, 1e-5, res=x, alpha=alpha, out2=xb)   # LN(alpha*x + attn)
             B.gemm(xb, L.w1, ff, bias=L.b1, gelu=True)

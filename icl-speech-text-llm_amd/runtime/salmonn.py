@@ -259,18 +259,6 @@ class SalmonnRuntime(CausalLMRuntimeMixin):
         if "llama" in parts:
             self.llama = LlamaHIP(pack_llama(sd, cfg.llama, self.device, consume=consume), self.device)
         self._graphs, self._graph_warm, self._graph_gen = {}, set(), 0
-        import os
-        if os.environ.get("ICL_PRECISE_ATTENTION") == "1":
-            self.set_precise_encoder_attention(True)
-
-    def set_precise_encoder_attention(self, on: bool) -> None:
-        """Two-term bf16 split of the softmax weights also in the encoders' head_dim-64 attention (the decoders' head_dim-128
-        attention always has it).  Default off: the speech stack is within ~1e-3 of the oracle as it is and the kernel is
-        vector-issue-bound; on, Whisper's distance from the oracle halves and its attention runs ~20 % slower."""
-        if self.whisper is not None:
-            self.whisper.precise_attention = bool(on)
-        if self.beats is not None:
-            self.beats.precise_attention = bool(on)
 
     # --------------------------------------------------------------------------------------------
     # K1-K8: SALMONN.encode_speech

@@ -130,8 +130,7 @@ typedef struct icl_attn_args {
   int32_t n_seqs, max_seqlen, n_heads, head_dim;
   int32_t causal, rel_span;
   float scale;
-  int32_t reserved;                            /* flags: bit 0 = precise P at head_dim 64, non-causal (two-term bf16 split of the
-                                                  softmax weights in the PV product, as head_dim 128 always does); other bits 0 */
+  int32_t reserved;                            /* 0 */
   int64_t kv_seq_stride, kv_head_stride;       /* both 0: K/V rows are packed like Q (row cu_seqlens[s] + j, head h at
                                                   column h*head_dim, row strides ldk / ldv).  Both > 0: K/V are read from a
                                                   cache, key j of (sequence s, head h) at K + s*kv_seq_stride +

@@ -267,28 +267,6 @@ def test_attn_fwd_d128_is_exact_up_to_the_output_rounding(B):
     assert differ < 0.01 and rel < 2e-4
 
 
-def test_attn_fwd_d64_precise_mode(B):
-    """flags bit 0 (`precise=True`): the head_dim-64 kernels take the two-term P as well — output == the rounded exact result
-    up to a fraction of a percent of the elements; the default one-term kernel differs in ~40 % of them (by one ulp)."""
-    D, H, L = 64, 2, 1500
-    qkv = _rand_bf16(L, 3 * H * D, seed=33)
-    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
-    cu_t = torch.tensor([0, L], dtype=torch.int32, device=DEV)
-    kvl = torch.tensor([1417], dtype=torch.int32, device=DEV)          # key padding: a masked, partial last tile
-    qs, ks, vs = (t.double().view(L, H, D).transpose(0, 1) for t in (q, k, v))
-    sc = (qs @ ks.transpose(1, 2) * D ** -0.5).masked_fill((torch.arange(L, device=DEV) >= 1417)[None, None, :], float("-inf"))
-    exact = (torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(L, H * D)
-    rounded = exact.to(torch.bfloat16)
-    frac = {}
-    for prec in (False, True):
-        out = torch.empty(L, H * D, dtype=torch.bfloat16, device=DEV)
-        B.attn_fwd(q, k, v, out, cu_t, L, H, D, D ** -0.5, kv_lens=kvl, precise=prec)
-        frac[prec] = float((out != rounded).double().mean())
-        assert float((out.double() - exact).abs().max()) <= 2e-2
-    print(f"attn D=64: elements differing from the rounded exact result: one-term P {frac[False]:.3f}, two-term P {frac[True]:.4f}")
-    assert frac[True] < 0.01 < frac[False]
-
-
 @pytest.mark.parametrize("D,H,causal", [(128, 3, True), (64, 2, False)])
 def test_attn_fwd_reads_kv_from_cache_layout(B, D, H, causal):
     """K / V addressed as [seq][head][pos][D] cache rows (what the fused QKV epilogue appends) == the packed-row form, bit

@@ -54,25 +54,6 @@ def test_whisper_encoder(env):
     assert eb < 2.5e-3 and ef < 6e-3            # measured on MI355X: 1.2e-3 / 2.7e-3
 
 
-def test_whisper_encoder_precise_attention(env):
-    """`set_precise_encoder_attention(True)`: the same chain with two-term P in its head_dim-64 attention is closer to the oracle."""
-    from oracle import audio_frontend as af, models as om
-    cfg, sd, rt = env
-    lens = [48000, 480000]
-    wav = _wavs(lens)
-    spec = torch.stack([torch.from_numpy(af.whisper_logmel(wav[i, :n].numpy())) for i, n in enumerate(lens)])
-    xt = rt.logmel.from_spectrogram(rt.ws, spec.to(DEV))
-    ref_b = om.whisper_encoder(sd, spec, cfg.whisper.n_heads, "speech_encoder.", rnd=om.bf16_round)
-    base = _rel(rt.whisper.forward(rt.ws, xt).view(2, 1500, -1), ref_b)
-    rt.set_precise_encoder_attention(True)
-    try:
-        prec = _rel(rt.whisper.forward(rt.ws, xt).view(2, 1500, -1), ref_b)
-    finally:
-        rt.set_precise_encoder_attention(False)
-    print(f"whisper vs bf16-rounding oracle: one-term P {base:.2e}, two-term P {prec:.2e}")
-    assert prec < base and prec < 1.5e-3
-
-
 def test_beats_encoder(env):
     from oracle import models as om
     cfg, sd, rt = env

@@ -18,8 +18,6 @@ out = torch.empty(total, H * D, dtype=torch.bfloat16, device=DEV)
 cu = torch.arange(0, total + 1, L, dtype=torch.int32, device=DEV)
 q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
 kw = {}
-if os.environ.get("ICL_ATTN_PRECISE") == "1":
-    kw["precise"] = True
 if which == "beats_bias":       # gated relative-position bias (BEATs): table [H, 2*span-1], gate [rows, H]
     kw = dict(rel_bias=torch.randn(H, 2 * L - 1, device=DEV), rel_gate=torch.rand(total, H, device=DEV) * 2, rel_span=L)
 for _ in range(3):
