@@ -100,7 +100,7 @@ def parse():
                          "the timed region; SURVEY.md §8d)")
     ap.add_argument("--no-through-plugin", action="store_true", help="skip the plugin-path leg")
     ap.add_argument("--plugin-workers", type=int, default=8)
-    ap.add_argument("--plugin-batch", type=int, default=64)
+    ap.add_argument("--plugin-batch", type=int, default=128, help="batch size of the plugin-path leg (same micro-batch as the runtime number)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c2s", "c4", "c5"],
                     help="BASELINE.md §4: c2 = headline (default); c2s = 5 speech exemplars; c4 = Qwen2-Audio HVB; "
                          "c5 = Llama2-13B VOXCELEB+HVB+VOXPOPULI round-robin")
@@ -369,7 +369,7 @@ def cpu_baseline_full(sd, cfg, wavs, idss, threads_all: int):
 # ======================================================================================================================
 # the plugin-path number ("dataloader/log-mel included")
 # ======================================================================================================================
-def through_plugin(args, dev, n_batches: int = 6, warm: int = 2):
+def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
     """ModelFactory.create_model -> SalmonProcessor -> DataLoader(num_workers) -> model.generate_output, timed the way the
     reference's loop counts examples (inference/inference.py:259-266,301-368; utils/performance_utils.py:96-122): H2D of the
     raw waveforms, the host prompt split + tokenisation, K1..K11 and batch_decode are all inside the timed region.  Also
