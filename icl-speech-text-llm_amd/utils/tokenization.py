@@ -157,5 +157,10 @@ def load_llama_tokenizer(llama_path: str, vocab_size: int = 32001):
         return tok
     if llama_path == "stand-in:subword":
         return SubwordStandInTokenizer(vocab_size)
+    if vocab_size >= 4096:
+        # one token per BYTE makes the reference's 5-shot prompts 1100-2000 positions long (HVB overflows max_pos 2048);
+        # the sub-word stand-in keeps them at the sentencepiece count (~3.9 characters per token)
+        logger.warning("llama_path %r is not a local directory: using the sub-word stand-in tokenizer (no real vocabulary)", llama_path)
+        return SubwordStandInTokenizer(vocab_size)
     logger.warning("llama_path %r is not a local directory: using the byte-level fallback tokenizer", llama_path)
     return ByteTokenizer(vocab_size)
