@@ -400,11 +400,11 @@ def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
     host_rate = n_host / (time.perf_counter() - t0)
     tracker, done, t_start, prompt_tokens = None, 0, None, []
     with torch.no_grad():
-        for b_i, batch in enumerate(loader()):
+        from icl_speech_text_llm_amd.utils.data_utils import device_prefetch
+        for b_i, batch in enumerate(device_prefetch(loader(), dev)):      # as the CLI does: batch i+1's H2D under batch i's kernels
             if b_i == warm:
                 torch.cuda.synchronize()
                 tracker, t_start = PerformanceTracker(log_interval=10 ** 9), time.perf_counter()
-            batch = {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
             batch["max_new_tokens"] = NEW_TOKENS
             t1 = time.perf_counter()
             out = model.generate_output(batch)

@@ -32,7 +32,7 @@ from ..data.model_processors import get_processor
 from ..data.synthetic_dataset import SyntheticICLDataset
 from ..data.dataset_factory import DatasetFactory
 from ..data.task_configs import DatasetType, parse_dataset_types, set_dataset_root
-from ..utils.data_utils import load_dataset
+from ..utils.data_utils import device_prefetch, load_dataset
 from ..models.model_factory import ModelFactory, load_finetuned_checkpoint
 from ..utils.evaluation_utils import clean_prediction, evaluate_predictions
 from ..utils.performance_utils import PerformanceTracker
@@ -202,11 +202,10 @@ def run_inference(args) -> Dict[str, Any]:
         ids_l, len_l, logit_l, idx_l = [], [], [], []
         failed_batches = 0
         with torch.no_grad():
-            for batch_idx, batch in enumerate(loader):
+            for batch_idx, batch in enumerate(device_prefetch(loader, args.device)):      # batch i+1's H2D under batch i's kernels
                 n_b = len(batch["prompt"])
                 b_idx = indices[batch_idx * args.batch_size: batch_idx * args.batch_size + n_b]
                 try:
-                    batch = {k: (v.to(args.device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
                     batch["max_new_tokens"] = args.max_new_tokens
                     t0 = time.time()
                     res = model.generate_ids(batch, want_first_logits=True)

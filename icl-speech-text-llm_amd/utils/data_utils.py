@@ -39,3 +39,41 @@ def clear_dataset_cache() -> int:
     n = len(_DATASET_CACHE)
     _DATASET_CACHE.clear()
     return n
+
+
+def device_prefetch(loader, device):
+    """Iterate ``loader`` one batch AHEAD: the tensors of batch i+1 are copied to ``device`` on a side stream (truly asynchronous
+    when the DataLoader pins its batches) while the caller's kernels for batch i run, instead of a blocking ``.to(device)``
+    between two batches (246 MB of raw audio per 128 utterances).  Yields batch dicts whose tensors live on ``device``; the
+    consumer's current stream waits for the copy of the batch it receives.  On a CPU device it is a plain pass-through."""
+    import torch
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        for batch in loader:
+            yield batch
+        return
+    side = torch.cuda.Stream(device=dev)
+
+    def ship(batch):
+        with torch.cuda.stream(side):
+            out = {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        ev = torch.cuda.Event()
+        ev.record(side)
+        return out, ev, batch          # keep the pinned host batch alive until its copy has been waited for
+
+    it = iter(loader)
+    try:
+        pending = ship(next(it))
+    except StopIteration:
+        return
+    while pending is not None:
+        cur, ev, _host = pending
+        try:
+            pending = ship(next(it))
+        except StopIteration:
+            pending = None
+        torch.cuda.current_stream(dev).wait_event(ev)
+        for v in cur.values():
+            if isinstance(v, torch.Tensor):
+                v.record_stream(torch.cuda.current_stream(dev))
+        yield cur
