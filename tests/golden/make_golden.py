@@ -585,7 +585,109 @@ def g10_dataset_items():
         shutil.rmtree(root, ignore_errors=True)
 
 
+def g14_reference_glue_sentencepiece():
+    """The reference's CustomSALMONN glue again, but with a REAL sentencepiece Llama tokenizer (the reference takes
+    `LlamaTokenizer.from_pretrained(llama_path, use_fast=False)` + a `[PAD]` token from the SALMONN object, custom_salmon.py:109):
+    word-boundary pieces, the dummy-prefix space in front of every separately tokenised prompt part, byte fallback for '\n'.
+    No Llama tokenizer files are reachable offline, so a 400-piece BPE model is trained here with sentencepiece on the task
+    prompts (Llama's own trainer settings: bpe, byte_fallback, identity normalisation, dummy prefix) and committed as the
+    fixture tests/golden/llama_spm/ ; what is pinned is the reference's splitting / per-part tokenisation / interleave / label
+    logic under such a tokenizer, not a vocabulary."""
+    import sentencepiece as spm
+    from transformers import AutoTokenizer
+    sys.path.insert(0, REF)
+    from data.model_processors import SalmonProcessor as RefProcessor
+    from data.master_config import DatasetType as RefDT, get_dataset_config as ref_cfg
+    rproc = RefProcessor.__new__(RefProcessor)
+    tmpl = ref_cfg(RefDT.VOXCELEB).prompt_template
+    ex = [{"text": f"example sentence number {i} about things", "label": ["positive", "negative", "neutral"][i % 3]} for i in range(5)]
+    d = os.path.join(HERE, "llama_spm")
+    os.makedirs(d, exist_ok=True)
+    corpus = os.path.join(d, "_corpus.txt")
+    lines = [rproc._format_default_prompt(tmpl, "the query sentence to classify", ex, m, f)
+             for m in ("speech_only", "text_only", "speech_and_text") for f in ("text", "speech")]
+    with open(corpus, "w") as f:
+        f.write("\n".join(l.replace("\n", " ") for l in lines * 20))
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(d, "tokenizer"), vocab_size=400, model_type="bpe",
+                                   character_coverage=1.0, byte_fallback=True, unk_id=0, bos_id=1, eos_id=2, pad_id=-1,
+                                   normalization_rule_name="identity", add_dummy_prefix=True, minloglevel=2)
+    os.remove(corpus)
+    os.remove(os.path.join(d, "tokenizer.vocab"))
+    with open(os.path.join(d, "tokenizer_config.json"), "w") as f:
+        json.dump({"tokenizer_class": "LlamaTokenizer", "legacy": True, "add_bos_token": True, "add_eos_token": False}, f)
+    tok = AutoTokenizer.from_pretrained(d, use_fast=False)
+    tok.add_special_tokens({"pad_token": "[PAD]"})
+    tok.padding_side = "right"
+    assert len(tok) == 401
+    llama = _tiny_llama(seed=14, vocab=401)
+    H = 64
+    torch.manual_seed(15)
+    proj = torch.randn(34, H) * 0.3
+
+    class StubSALMONN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.llama_model = llama
+            self.llama_tokenizer = tok
+
+        @classmethod
+        def from_config(cls, cfg):
+            return cls()
+
+        def encode_speech(self, spectrogram=None, raw_wav=None, audio_padding_mask=None):
+            B = spectrogram.shape[0]
+            feat = spectrogram.float().mean(dim=1)[:, :88 * 34].reshape(B, 88, 34)
+            return torch.tanh(feat @ proj), torch.ones(B, 88, dtype=torch.long)
+
+    for name in ("SALMONN", "SALMONN.models", "SALMONN.models.salmonn_org"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["SALMONN.models.salmonn_org"].SALMONN = StubSALMONN
+    sys.modules.pop("models.custom_salmon", None)
+    from models.custom_salmon import CustomSALMONN as RefSALMONN
+    ref = RefSALMONN(lora=False, device=torch.device("cpu"))
+    torch.manual_seed(16)
+    cases = {}
+    for case, (mode, few, nspeech_ex) in {"text_only": ("text_only", "text", 0), "speech_text_ex": ("speech_only", "text", 0),
+                                           "speech_speech_ex": ("speech_only", "speech", 2)}.items():
+        exs = ex[:nspeech_ex] if few == "speech" else ex
+        prompt = rproc._format_default_prompt(tmpl, "the query sentence to classify", exs, mode, few)
+        samples = {"prompt": [prompt], "completion": ["positive"], "num_examples": torch.tensor([len(exs) if few == "speech" else 0])}
+        if mode != "text_only":
+            samples["spectrogram"] = torch.randn(1, 80, 3000) * 0.5
+            samples["raw_wav"] = torch.zeros(1, 16000)
+            samples["padding_mask"] = torch.zeros(1, 16000, dtype=torch.bool)
+        if few == "speech":
+            samples["example_spectrograms"] = torch.randn(1, nspeech_ex, 80, 3000) * 0.5
+            samples["example_wavs"] = torch.zeros(1, nspeech_ex, 16000)
+            samples["example_padding_masks"] = torch.zeros(1, nspeech_ex, 16000, dtype=torch.bool)
+        with torch.no_grad():
+            ref.batch_counter = 1
+            sp, sa, ee, ea = ref.get_speech_embeddings(dict(samples))
+            wrapped, watts = ref.custom_prompt_wrap(sp, sa, samples["prompt"], samples["num_examples"], ee, ea)
+            fwd = ref.forward(dict(samples))
+            gen = ref.generate_output(dict(samples))
+            gen_ids = ref.llama_model.generate(inputs_embeds=wrapped, attention_mask=watts, max_new_tokens=10, num_beams=1,
+                                               do_sample=False, min_length=1, pad_token_id=tok.pad_token_id,
+                                               eos_token_id=tok.eos_token_id)
+        arrs = dict(wrapped=wrapped[0], logits_tail=fwd["logits"][0, -12:], labels=fwd["labels"][0], loss=fwd["loss"],
+                    gen_ids=gen_ids[0])
+        if sp is not None:
+            arrs["speech"] = sp[0]
+        if ee is not None:
+            arrs["examples"] = torch.stack(ee[0])
+        cases[case] = {"prompt": prompt, "completion": "positive", "generated_text": gen[0],
+                       "num_examples": int(samples["num_examples"][0]), "S": int(wrapped.shape[1])}
+        save(f"glue_spm_{case}.npz", **arrs)
+    save("glue_spm_llama.npz", **{"w:" + k: v for k, v in llama.state_dict().items()})
+    with open(os.path.join(HERE, "glue_spm_cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                  # e.g. `make_golden.py g14_reference_glue_sentencepiece`: regenerate one family only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_logmel()
     g2_whisper()
     g3_qformer()
@@ -598,3 +700,4 @@ if __name__ == "__main__":
     g11_sampling()
     g12_qwen_prompts()
     g13_performance_tracker()
+    g14_reference_glue_sentencepiece()

@@ -116,6 +116,48 @@ def test_prompt_wrap_labels_logits_generate_match_reference_glue(case):
     assert tok.batch_decode(ids, skip_special_tokens=True)[0] == meta["generated_text"]
 
 
+@pytest.mark.parametrize("case", ["text_only", "speech_text_ex", "speech_speech_ex"])
+def test_reference_glue_with_a_sentencepiece_llama_tokenizer(case):
+    """The same pin as above under a REAL sentencepiece Llama tokenizer (`load_llama_tokenizer` on a folder holding
+    `tokenizer.model`, + `[PAD]`, the reference's `LlamaTokenizer.from_pretrained(llama_path, use_fast=False)` path): word-boundary
+    pieces, the dummy-prefix space in front of every separately tokenised part, byte fallback — the reference's CustomSALMONN
+    tokenised each prompt part with it (tests/golden/make_golden.py::g14) and our split / per-part tokenisation / interleave /
+    labels must land on exactly its wrapped sequence, labels, logits and greedy ids."""
+    from icl_speech_text_llm_amd.models.custom_salmon import build_labels, interleave_plan, split_prompt
+    from icl_speech_text_llm_amd.utils.tokenization import load_llama_tokenizer
+    from oracle import models as om
+    meta = json.load(open(os.path.join(G, "glue_spm_cases.json")))[case]
+    a, _ = _load(f"glue_spm_{case}.npz")
+    _, sd = _load("glue_spm_llama.npz")
+    llm = om.LlamaOracle(sd, n_heads=2, rms_eps=1e-5)
+    tok = load_llama_tokenizer(os.path.join(G, "llama_spm"), 401)
+    assert len(tok) == 401 and tok.pad_token_id == 400 and type(tok).__name__.startswith("LlamaTokenizer")
+    assert tok.convert_ids_to_tokens(tok("Output: positive", add_special_tokens=False)["input_ids"])[0] == "\u2581Output"
+    speech = torch.from_numpy(a["speech"]) if "speech" in a else None
+    examples = torch.from_numpy(a["examples"]) if "examples" in a else None
+    n_ex = meta["num_examples"]
+    parts = split_prompt(meta["prompt"], n_ex, examples is not None)
+    pieces = []
+    for kind, i in interleave_plan(len(parts), n_ex, None if examples is None else len(examples), speech is not None):
+        if kind == "text":
+            ids = tok(parts[i], padding="longest", return_tensors="pt", add_special_tokens=False)["input_ids"].reshape(-1)   # as CustomSALMONN._segments does
+            pieces.append(llm.embed(ids.long()))
+        else:
+            pieces.append(speech if kind == "speech" else examples[i])
+    wrapped = torch.cat(pieces, 0)
+    assert wrapped.shape[0] == meta["S"]
+    assert torch.equal(wrapped, torch.from_numpy(a["wrapped"]))
+    tgt = tok([meta["completion"]], padding="longest", return_tensors="pt", add_special_tokens=False, return_attention_mask=True)
+    labels = build_labels(wrapped.shape[0], tgt["input_ids"], tgt["attention_mask"])
+    assert torch.equal(labels[0], torch.from_numpy(a["labels"]))
+    logits, loss = llm.forward(torch.cat([wrapped, llm.embed(tgt["input_ids"][0])], 0)[None], labels)
+    assert np.abs(logits[0, -12:].numpy() - a["logits_tail"]).max() < 5e-4
+    assert abs(float(loss) - float(a["loss"])) < 2e-4
+    ids = llm.generate_greedy(wrapped[None], 10, eos_id=tok.eos_token_id, pad_id=tok.pad_token_id)
+    assert ids[0].tolist() == a["gen_ids"].tolist()
+    assert tok.batch_decode(ids, skip_special_tokens=True)[0] == meta["generated_text"]
+
+
 def test_qwen2_audio_matches_hf():
     """Oracle audio tower (key padding, AvgPool, ln_post, projector) + scatter + Qwen2 LM (QKV bias) vs HF
     Qwen2AudioForConditionalGeneration on a 2-audio prompt."""
