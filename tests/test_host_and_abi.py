@@ -162,7 +162,7 @@ def test_data_parallel_sharding_gloo_world2(tmp_path):
     failing on rank 1 the surviving records keep their places and the lost indices are reported, not shifted over."""
     script = tmp_path / "dp.py"
     script.write_text(_DP_SCRIPT)
-    for d in ("w1", "w2", "w2f"):
+    for d in ("w1", "w2", "w2f", "w3"):
         (tmp_path / d).mkdir()
     a = _run_dp(script, tmp_path / "w1", 1, 0)
     b = _run_dp(script, tmp_path / "w2", 2, 29611)
@@ -170,6 +170,9 @@ def test_data_parallel_sharding_gloo_world2(tmp_path):
     assert a["texts"] == b["texts"] and a["preds"] == b["preds"]
     assert a["label_logits"][0] and a["label_logits"] == b["label_logits"]       # bf16 slice of the first-step logits, by label
     assert any(f.endswith("_metrics.json") for f in os.listdir(tmp_path / "w2"))
+    d3 = _run_dp(script, tmp_path / "w3", 3, 29615)                 # 10 utterances over 3 ranks: 4 + 3 + 3, padded rows carry index -1
+    assert d3["n"] == 10 and d3["missing"] == [] and d3["texts"] == a["texts"] and d3["preds"] == a["preds"]
+    assert d3["label_logits"] == a["label_logits"]
     c = _run_dp(script, tmp_path / "w2f", 2, 29613, {"DP_FAIL": "1"})
     assert c["failed"] == 1 and c["missing"] == [5, 7] and c["n"] == 8     # rank 1 holds 1,3,5,7,9: its 2nd batch is (5, 7)
     keep = [i for i in range(10) if i not in (5, 7)]
