@@ -18,6 +18,7 @@
 // Variable-length packing (cu_seqlens), causal masking, a key-padding length per sequence and the
 // BEATs gated relative-position bias are handled in the score stage.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -38,28 +39,31 @@ struct AttnParams {
 
 constexpr float NEG_BIG = -1.0e30f;
 
-// fmaxf on MFMA outputs makes hipcc prepend a canonicalising v_max per operand (3 instructions per max of 2); the scores
-// are never signalling NaNs, so take the raw 3-input maximum: 16 instructions for the 32 scores of a tile instead of 57.
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ float max2_raw(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float max32_raw(const f32x16& a, const f32x16& b) {
-  float m = max3_raw(a[0], a[1], a[2]);
+// Row maxima use plain fmaxf (hipcc fuses the chain into v_max3_f32 and canonicalises only the first pair).  They must NOT be
+// inline asm: reading an MFMA result from a vector instruction needs software wait states on gfx950, hipcc's hazard
+// recogniser does not look inside asm statements, and its scheduler is free to move one right behind the MFMA that
+// produces its operand — the row maximum then comes out stale now and then (harmless to the value of a softmax, fatal to
+// bit-reproducibility; caught by the packed-rows == cache-rows test).
+__device__ __forceinline__ float max32(const f32x16& a, const f32x16& b) {
+  float m = __builtin_fmaxf(a[0], a[1]);
 #pragma unroll
-  for (int r = 3; r + 1 < 16; r += 2) m = max3_raw(m, a[r], a[r + 1]);
-  m = max3_raw(m, a[15], b[0]);
+  for (int r = 2; r < 16; ++r) m = __builtin_fmaxf(m, a[r]);
 #pragma unroll
-  for (int r = 1; r + 1 < 16; r += 2) m = max3_raw(m, b[r], b[r + 1]);
-  return max2_raw(m, b[15]);
+  for (int r = 0; r < 16; ++r) m = __builtin_fmaxf(m, b[r]);
+  return m;
 }
 constexpr float LOG2E = 1.4426950408889634f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// max of a value with its partner in the other half of the wave (lane ^ 32), in every lane: one v_permlane32_swap (lanes
+// 32..63 of the first operand trade places with lanes 0..31 of the second) instead of a ds_bpermute round trip through LDS
+// in the middle of the softmax's dependent chain
+__device__ __forceinline__ float max_xhalf(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned lo = r[0], hi = r[1];   // (a bit_cast applied to r[1] directly reads element 0 with this hipcc)
+  return __builtin_fmaxf(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
+}
 
 template <int D, bool CAUSAL, bool BIAS>
 __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
@@ -211,7 +215,11 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
   __syncthreads();
   int cur = 0;            // ring slot of tile t
 
-  for (int t = 0; t < n_tiles; ++t) {
+  // One KV tile.  MAYMASK = false is the interior form: every key of the tile is visible to every query of the wave, so
+  // the body carries no mask, no per-q-block branch and none of the key-index arithmetic hipcc otherwise hoists above the
+  // "need_mask" test and executes on every tile (35 vector instructions per iteration of the D = 64 kernel).
+  auto tile = [&](const int t, auto maymask_c) {
+    constexpr bool MAYMASK = decltype(maymask_c)::value;
     // unconditional (the last iteration stages its own tile again, into the idle buffer): a conditional issue makes hipcc's
     // waitcnt pass merge the two paths pessimistically
     int nxt = cur + AHEAD;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
     bool any_active = false;
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) {
-      active[qi] = !CAUSAL || (k0 <= qw[qi] + 31);
+      active[qi] = !MAYMASK || !CAUSAL || (k0 <= qw[qi] + 31);
       any_active |= active[qi];
     }
     if (any_active) {
@@ -266,23 +274,33 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
           continue;
         }
         // need_mask is wave-uniform: interior tiles take the branch-free fast path (raw v_exp_f32, one FMA per score)
-        const bool need_mask = __builtin_amdgcn_readfirstlane((int)((k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw[qi]))));
+        const bool need_mask =
+            MAYMASK && __builtin_amdgcn_readfirstlane((int)((k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw[qi]))));
         float psum = 0.f, alpha;
         if (!BIAS && !need_mask) {
-          float tmax = max32_raw(s_acc[qi][0], s_acc[qi][1]);
-          tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;   // scale > 0: max commutes with the scaling
-          const float m_new = max2_raw(m_run[qi], tmax);
+          float tmax = max32(s_acc[qi][0], s_acc[qi][1]);
+          tmax = max_xhalf(tmax) * p.scale_log2e;   // scale > 0: max commutes with the scaling
+          const float m_new = __builtin_fmaxf(m_run[qi], tmax);
           alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
           m_run[qi] = m_new;
+          // two scores per vector instruction where the ISA has a packed f32 form (v_pk_fma_f32, v_pk_add_f32: the
+          // accumulator registers are consecutive, so pairs are free); the row sum runs as two partial sums
+          const f32x2 sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-m_new, -m_new};
+          f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float e = __builtin_amdgcn_exp2f(fmaf(s_acc[qi][kb][r], p.scale_log2e, -m_new));
-              psum += e;
-              pf[qi][kb][r >> 3][r & 7] = (__bf16)e;
-              if (P2) pl[qi][kb][r >> 3][r & 7] = (__bf16)(e - (float)pf[qi][kb][r >> 3][r & 7]);
+            for (int r = 0; r < 16; r += 2) {
+              const f32x2 x = f32x2{s_acc[qi][kb][r], s_acc[qi][kb][r + 1]} * sc2 + nm2;
+              const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+              ps2 += e;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                pf[qi][kb][r >> 3][(r & 7) + h] = (__bf16)e[h];
+                if (P2) pl[qi][kb][r >> 3][(r & 7) + h] = (__bf16)(e[h] - (float)pf[qi][kb][r >> 3][(r & 7) + h]);
+              }
             }
+          psum = ps2[0] + ps2[1];
         } else {
           float tmax;
           const float* win = nullptr;
@@ -311,9 +329,8 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
               s_acc[qi][kb][r] = v;
             }
           }
-          tmax = max32_raw(s_acc[qi][0], s_acc[qi][1]);
-          tmax = max2_raw(tmax, __shfl_xor(tmax, 32, 64));
-          const float m_new = max2_raw(m_run[qi], tmax);
+          tmax = max_xhalf(max32(s_acc[qi][0], s_acc[qi][1]));
+          const float m_new = __builtin_fmaxf(m_run[qi], tmax);
           alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
           m_run[qi] = m_new;
 #pragma unroll
@@ -363,7 +380,15 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
     wait_oldest_tile();   // this wave's share of tile t+1 has landed
     __syncthreads();
     cur = cur + 1 == NBUF ? 0 : cur + 1;
+  };
+  // interior tiles first (whole tile inside kv_len and, when causal, at or below the wave's first query), then the rest;
+  // the split is per wave, every wave still passes one barrier per tile
+  int t = 0;
+  if constexpr (!BIAS) {
+    const int n_plain = min(n_tiles, CAUSAL ? min(kvlen, qw[0] + 1) >> 6 : kvlen >> 6);
+    for (; t < n_plain; ++t) tile(t, std::false_type{});
   }
+  for (; t < n_tiles; ++t) tile(t, std::true_type{});
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l -------------------------------------------------------------
   // A lane owns one query ROW, so direct stores are 8-B pieces at a row stride: every store instruction touches 64 cache
