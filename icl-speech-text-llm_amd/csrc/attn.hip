@@ -245,15 +245,35 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) s_acc[qi][kb][r] = 0.f;
+      // K fragments by inline-asm ds_read_b128 with hand-counted waits, LA k-steps ahead of the MFMAs that consume them
+      // (same reason as the V reads below: a compiler-visible LDS read makes hipcc wait for every LDS-DMA in flight).
+      // k-step outer, key-half inner: each accumulator still sums its k-steps in ascending order.
+      {
+        constexpr int LA = QB == 2 ? 1 : 2;
+        bf16x8 kf[LA + 1][2];
+        auto read_k = [&](int ks, int slot) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const char* kp = k_lds + kb * 32 * ROWB;
+          for (int kb = 0; kb < 2; ++kb) {
+            const unsigned a = (unsigned)(uintptr_t)(k_lds + kb * 32 * ROWB + k_off[ks]);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(kf[slot][kb]) : "v"(a));
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < LA; ++i) read_k(i, i);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 kf = *(const bf16x8*)(kp + k_off[ks]);
+          const int slot = ks % (LA + 1);
+          if (ks + LA < KS) read_k(ks + LA, (ks + LA) % (LA + 1));
+          const int newer = 2 * (KS - 1 - ks < LA ? KS - 1 - ks : LA);      // reads issued after this k-step's pair
+          if (newer == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[slot][0]), "+v"(kf[slot][1]));
+          else if (newer == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kf[slot][0]), "+v"(kf[slot][1]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[slot][0]), "+v"(kf[slot][1]));
 #pragma unroll
-          for (int qi = 0; qi < QB; ++qi)
-            if (active[qi]) s_acc[qi][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][ks], s_acc[qi][kb], 0, 0, 0);
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+              if (active[qi])
+                s_acc[qi][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[slot][kb], qf[qi][ks], s_acc[qi][kb], 0, 0, 0);
         }
       }
       // ---- scores -> base-2 logits, bias, mask, online softmax; per q-block ---------------------------------------
@@ -355,17 +375,37 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
         }
       }
       // ---- O^T += V^T P^T: every transposed V fragment is read once and feeds all q-blocks ----------------------------
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+      // The transposed reads are inline asm with hand-counted lgkmcnt waits: through the builtin, hipcc's waitcnt pass cannot
+      // tell the read from the LDS-DMA writes in flight (the tiles staged AHEAD) and puts s_waitcnt vmcnt(0) in front of the
+      // first one, which turns the ring back into "wait for everything you just issued".  Tile t itself is known to have
+      // landed (counted wait + barrier at the end of the previous iteration).  One unit (4 reads) is kept in flight ahead of
+      // the MFMAs; the wait statement carries the fragments as operands so the MFMAs cannot be scheduled above it.
+      {
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        // unit u = (d-block, key half): two fragments (k-steps s = 0, 1) = 4 reads, 8 VGPRs; one unit in flight ahead
+        s16x4 vr[2][2][2];
+        auto read_unit = [&](int u, int slot) {
+          const int d = u >> 1, kb = u & 1;
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            const char* vp = v_lds + (kb * 32 + 16 * s) * ROWB + tr_off[d];
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * ROWB));
-            typedef __attribute__((ext_vector_type(8))) short s16x8;
-            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const unsigned a = (unsigned)(uintptr_t)(v_lds + (kb * 32 + 16 * s) * ROWB + tr_off[d]);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vr[slot][s][0]) : "v"(a));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[slot][s][1]) : "v"(a), "n"(8 * ROWB));
+          }
+        };
+        read_unit(0, 0);
+#pragma unroll
+        for (int u = 0; u < 2 * DB; ++u) {
+          const int slot = u & 1, d = u >> 1, kb = u & 1;
+          if (u + 1 < 2 * DB) {
+            read_unit(u + 1, slot ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vr[slot][0][0]), "+v"(vr[slot][0][1]), "+v"(vr[slot][1][0]), "+v"(vr[slot][1][1]));
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[slot][0][0]), "+v"(vr[slot][0][1]), "+v"(vr[slot][1][0]), "+v"(vr[slot][1][1]));
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const s16x8 both = __builtin_shufflevector(vr[slot][s][0], vr[slot][s][1], 0, 1, 2, 3, 4, 5, 6, 7);
             const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi)
@@ -378,7 +418,10 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
       }
     }
     wait_oldest_tile();   // this wave's share of tile t+1 has landed
-    __syncthreads();
+    // bare s_barrier, not __syncthreads(): the fences of the latter make hipcc drain every LDS-DMA in flight (vmcnt(0)).
+    // What the barrier orders is covered by hand: this wave's DMA share of the next tile (counted wait above) and its LDS
+    // reads of tile t (every asm read was waited for before the MFMA that consumed it)
+    __builtin_amdgcn_s_barrier();
     cur = cur + 1 == NBUF ? 0 : cur + 1;
   };
   // interior tiles first (whole tile inside kv_len and, when causal, at or below the wave's first query), then the rest;
@@ -389,6 +432,9 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
     for (; t < n_plain; ++t) tile(t, std::false_type{});
   }
   for (; t < n_tiles; ++t) tile(t, std::true_type{});
+  // the last iterations staged (again) into ring slots the epilogue is about to reuse: every wave's LDS-DMA must have landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l -------------------------------------------------------------
   // A lane owns one query ROW, so direct stores are 8-B pieces at a row stride: every store instruction touches 64 cache
