@@ -19,9 +19,6 @@
 // BEATs gated relative-position bias are handled in the score stage.
 #include "common.h"
 #include <type_traits>
-#ifndef ICL_ATTN_ABL
-#define ICL_ATTN_ABL 0   // diagnostic builds of the pipelined kernel (tools/attn_ablate.sh); 0 = the product
-#endif
 
 namespace {
 
@@ -70,10 +67,12 @@ __device__ __forceinline__ float max_xhalf(float v) {
 
 template <int D, bool CAUSAL, bool BIAS>
 __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kernel(AttnParams p) {
-  // 32-query blocks per wave: at D = 64 two of them share every K and V fragment read, every staged byte and every
-  // barrier (the loop is issue-bound, not MFMA-bound); the gated-bias variant keeps one (measured: its longer per-score
-  // sequence wants the third wave per SIMD more than the sharing, 407 vs 385 TF/s on the BEATs shape)
-  constexpr int QB = (D == 64 && !BIAS) ? 2 : 1;
+  // 32-query blocks per wave.  D = 64 without bias runs attn_fwd_il64_kernel below (two blocks per wave sharing every K / V
+  // fragment, stages interleaved by hand); this kernel serves D = 128 and the gated-bias variant, one block per wave
+  // (measured for the bias variant: its longer per-score sequence wants the third wave per SIMD more than the sharing,
+  // 407 vs 385 TF/s on the BEATs shape).  The QB > 1 paths are kept: they are the reference the il64 kernel was checked
+  // against bit for bit.
+  constexpr int QB = 1;
   // D = 128 (the decoders' prefill / teacher-forced attention): P enters the PV product as a TWO-term bf16 split,
   // P = hi + lo with hi = bf16(P), lo = bf16(P - hi) (16 mantissa bits instead of 8), at the price of a second PV MFMA.
   // The oracle's softmax weights are f32: with one-term bf16 P this single rounding point alone put the decoder logits
@@ -495,24 +494,25 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
 
 
 // =====================================================================================================================
-// D = 64 without bias (Whisper / Qwen2-Audio encoder, Q-Former): SOFTWARE-PIPELINED form of the kernel above.
+// D = 64 without bias (Whisper / Qwen2-Audio encoder, Q-Former): the kernel above with its stages INTERLEAVED by hand.
 //
-// Why: on one SIMD the MFMA stream of one wave and the vector stream of ANOTHER wave do not overlap (DESIGN.md §4.2,
-// tools/ubench/overlap.hip) — only vector instructions placed between the MFMAs of the SAME wave run in their shadow.  In the
-// kernel above a tile is  QK^T -> softmax -> PV  with each stage depending on the one before, so there is nothing for the
-// scheduler to put between the MFMAs and the kernel's time is the sum of its phases.  Here iteration t holds two
-// INDEPENDENT chains in one basic block:  S(t+1) = K(t+1) Q^T  (8 MFMAs, into the other score buffer) and  softmax(S(t)),
-// followed by  O += V(t)^T P(t).  One 32-query block per wave keeps the doubled score buffer inside 256 registers at two
-// waves per SIMD; the loop is unrolled by two so the buffers swap roles without copies.  Arithmetic is that of the kernel
-// above, operation for operation (same k-step order per accumulator, same softmax formulas), so the two agree bit for bit.
-//
-// Ring: 3 slots of (K tile, V tile).  Iteration t reads K(t+1) and V(t), and stages tile t+2 into the slot tile t-1 left
-// (its V was last read in iteration t-1, behind a barrier).  The DMA issued at the top of iteration t is waited for at its end
-// — a whole iteration later — and the barrier that follows publishes it for iteration t+1's K(t+2) reads.
+// Measured on gfx950 (tools/ubench/shadow.hip, profiles/r02_ubench_mfma_shadow.txt): vector work overlaps an MFMA only when
+// it comes from the SAME wave and sits right behind it in the instruction stream; v_exp / v_cvt_pk_bf16 / v_max3 / v_add hide
+// 50-80 % of their cost there, the packed f32 forms (v_pk_fma / v_pk_add / v_pk_mul) hide nothing (they cost MORE next to
+// an MFMA than alone).  The generic kernel's tile is QK^T -> softmax -> PV, each stage waiting for the one before, so nothing
+// can sit behind its MFMAs and its time is the sum of its phases.  Here a wave's two 32-query blocks are staggered:
+//     A   S0 = K Q0^T                      (8 MFMAs)
+//     B   S1 = K Q1^T                      (8 MFMAs)   with   exponentials of block 0
+//     C   O0 += V^T P0                     (8 MFMAs)   with   exponentials of block 1
+//     D   O1 += V^T P1                     (8 MFMAs)
+// K and V fragments are read once per tile into registers (the V fragments take over the K fragments' registers) and feed
+// both blocks, exactly as above; the scalar (non-packed) score math keeps the shadow usable.  Arithmetic per query is that of
+// the generic kernel operation for operation (k-step order per accumulator, softmax formulas, sequential row sum).
+// (the causal form is not on any model's path here: it gets the registers it asks for instead of spilling at two waves per SIMD)
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pipe64_kernel(AttnParams p) {
-  constexpr int D = 64, BQ = 128, ROWB = D * 2, KS = D / 16, DB = D / 32, CPR = D / 8;
-  constexpr int NCH = 64 * CPR / 256, RPI = 64 / CPR, BUF = 2 * 64 * ROWB, NBUF = 4;
+__global__ __launch_bounds__(256, CAUSAL ? 1 : 2) void attn_fwd_il64_kernel(AttnParams p) {
+  constexpr int D = 64, QB = 2, BQ = 128 * QB, ROWB = D * 2, KS = D / 16, DB = D / 32, CPR = D / 8;
+  constexpr int NCH = 64 * CPR / 256, RPI = 64 / CPR, BUF = 2 * 64 * ROWB, NBUF = 3;
   __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -531,13 +531,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe64_kernel(AttnParams p) {
   const int kv_end = CAUSAL ? min(kvlen, qb + BQ) : kvlen;
   const int n_tiles = (kv_end + 63) >> 6;
 
-  const int qw = qb + wave * 32, qpos = qw + ql;
-  bf16x8 qf[KS];
-  {
-    const int qrow = min(qpos, len - 1);
+  int qw[QB], qpos[QB];
+  bf16x8 qf[QB][KS];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    qw[qi] = qb + (wave * QB + qi) * 32;
+    qpos[qi] = qw[qi] + ql;
+    const int qrow = min(qpos[qi], len - 1);
     const unsigned short* qp = p.Q + (int64_t)(row0 + qrow) * p.ldq + head * D + hh * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = *(const bf16x8*)(qp + ks * 16);
   }
 
   // ---- staging: LDS-DMA with source-side swizzle (identical to the kernel above) ---------------------------------------
@@ -581,13 +584,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe64_kernel(AttnParams p) {
     }
   };
 
-  f32x16 o_acc[DB];
-  float m_run = NEG_BIG, l_run = 0.f;
+  f32x16 o_acc[QB][DB];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-  for (int d = 0; d < DB; ++d)
+  for (int qi = 0; qi < QB; ++qi) {
+    m_run[qi] = NEG_BIG;
+    l_run[qi] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
-
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[qi][d][r] = 0.f;
+  }
   int k_off[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) k_off[ks] = ql * ROWB + (((2 * ks + hh) ^ f_k(ql)) << 4);
@@ -599,248 +606,222 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe64_kernel(AttnParams p) {
     for (int d = 0; d < DB; ++d) tr_off[d] = (4 * hh + q) * ROWB + (((4 * d + c2) ^ f_v(q)) << 4) + (lane & 1) * 8;
   }
 
-  // S^T = K Q^T for the K tile at k_lds: fragments by asm ds_read_b128 one k-step ahead, counted waits
-  auto qk = [&](const char* k_lds, f32x16 (&s)[2]) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-    bf16x8 kf[2][2];
-    auto read_k = [&](int ks, int slot) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const unsigned a = (unsigned)(uintptr_t)(k_lds + kb * 32 * ROWB + k_off[ks]);
-#if ICL_ATTN_ABL == 1
-        asm volatile("; no read %0 %1" : "=v"(kf[slot][kb]) : "v"(a));   // (diagnostic) no LDS read
-#else
-        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[slot][kb]) : "v"(a));
-#endif
-      }
-    };
-    read_k(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int slot = ks & 1;
-      if (ks + 1 < KS) {
-        read_k(ks + 1, slot ^ 1);
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kf[slot][0]), "+v"(kf[slot][1]));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[slot][0]), "+v"(kf[slot][1]));
-      }
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#if ICL_ATTN_ABL == 2
-        s[kb][ks] += (float)kf[slot][kb][0] * (float)qf[ks][0];   // (diagnostic) no MFMA
-#else
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[slot][kb], qf[ks], s[kb], 0, 0, 0);
-#endif
-      }
-    }
-  };
-
-  // online softmax of one score tile, in two parts so that the wave-uniform "rescale O?" branch sits BEFORE the block that
-  // holds the MFMAs: head = row maximum, alpha, rescale; tail = exponentials -> P (bf16 B-operand fragments), row sum
-  auto softmax_head = [&](f32x16 (&s)[2], const int k0, auto maymask_c) -> bool {
+  // softmax of one 32-query block in two parts: head = row maximum, alpha, rescale of O (its wave-uniform branch closes a
+  // basic block, so it sits BEFORE the stretch that holds MFMAs); tail = exponentials -> P fragments, row sum
+  auto sm_head = [&](const int qi, f32x16 (&s)[2], const int k0, auto maymask_c) -> bool {
     constexpr bool MAYMASK = decltype(maymask_c)::value;
-    const bool need_mask = MAYMASK && __builtin_amdgcn_readfirstlane((int)((k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw))));
+    const bool need_mask =
+        MAYMASK && __builtin_amdgcn_readfirstlane((int)((k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw[qi]))));
     float tmax;
     if (!need_mask) {
-      tmax = max_xhalf(max32(s[0], s[1])) * p.scale_log2e;
+      tmax = max_xhalf(max32(s[0], s[1])) * p.scale_log2e;   // scale > 0: max commutes with the scaling
     } else {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const bool ok = (key < kvlen) && (!CAUSAL || key <= qpos);
+          const bool ok = (key < kvlen) && (!CAUSAL || key <= qpos[qi]);
           s[kb][r] = ok ? s[kb][r] * p.scale_log2e : NEG_BIG;
         }
       tmax = max_xhalf(max32(s[0], s[1]));
     }
-    const float m_new = __builtin_fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    l_run *= alpha;
+    const float m_new = __builtin_fmaxf(m_run[qi], tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+    m_run[qi] = m_new;
+    l_run[qi] *= alpha;
     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
       for (int d = 0; d < DB; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o_acc[qi][d][r] *= alpha;
     }
     return need_mask;
   };
-  auto softmax_tail = [&](f32x16 (&s)[2], const bool need_mask, bf16x8 (&pf)[2][2]) {
-    float psum;
+  auto sm_tail = [&](const int qi, f32x16 (&s)[2], const bool need_mask, bf16x8 (&pf)[2][2]) {
+    float psum = 0.f;
+    const float m = m_run[qi];
     if (!need_mask) {
-      const f32x2 sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-m_run, -m_run};
-      f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 x = f32x2{s[kb][r], s[kb][r + 1]} * sc2 + nm2;
-          const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-          ps2 += e;
-          pf[kb][r >> 3][r & 7] = (__bf16)e[0];
-          pf[kb][r >> 3][(r & 7) + 1] = (__bf16)e[1];
-        }
-      psum = ps2[0] + ps2[1];
-    } else {
-      psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float e = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2e, -m));
+          psum += e;
+          pf[kb][r >> 3][r & 7] = (__bf16)e;
+        }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float e = __builtin_amdgcn_exp2f(s[kb][r] - m);
           e = (s[kb][r] <= NEG_BIG * 0.5f) ? 0.f : e;
           psum += e;
           pf[kb][r >> 3][r & 7] = (__bf16)e;
         }
     }
-    l_run += psum;
+    l_run[qi] += psum;
   };
 
-  // O^T += V^T P^T with the V tile at v_lds: transposed fragments by asm; unit = one key half (both d-blocks, both k-steps:
-  // 8 reads, 16 VGPRs), one unit in flight ahead; the MFMAs of a unit alternate between the two O accumulators
-  auto pv = [&](const char* v_lds, bf16x8 (&pf)[2][2]) {
+  stage_tile(0, 0);
+  stage_tile(min(1, n_tiles - 1), 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+
+  auto tile = [&](const int t, auto maymask_c) {
+    int nxt = cur + 2;
+    if (nxt >= NBUF) nxt -= NBUF;
+    stage_tile(min(t + 2, n_tiles - 1), nxt);
+    const int k0 = t * 64;
+    const char* k_lds = lds + cur * BUF;
+    const char* v_lds = k_lds + 64 * ROWB;
+    // all eight K fragments of the tile, k-step major (asm reads, counted waits: see the generic kernel)
+    bf16x8 kf[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const unsigned a = (unsigned)(uintptr_t)(k_lds + kb * 32 * ROWB + k_off[ks]);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[ks][kb]) : "v"(a));
+      }
+    f32x16 s0[2], s1[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s0[kb][r] = s1[kb][r] = 0.f;
+    // ---- A: S0 = K Q0^T ------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(kf[0][0]), "+v"(kf[0][1]));
+      if (ks == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[1][0]), "+v"(kf[1][1]));
+      if (ks == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kf[2][0]), "+v"(kf[2][1]));
+      if (ks == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[3][0]), "+v"(kf[3][1]));
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) s0[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks][kb], qf[0][ks], s0[kb], 0, 0, 0);
+    }
+    const bool nm0 = sm_head(0, s0, k0, maymask_c);
+    // ---- B: S1 = K Q1^T  with  the exponentials of block 0 ---------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) s1[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks][kb], qf[1][ks], s1[kb], 0, 0, 0);
+    bf16x8 pf0[2][2], pf1[2][2];
+    sm_tail(0, s0, nm0, pf0);
+    // pin: without it hipcc sinks block 0's exponentials below the next wave-uniform branch, next to their first use (C),
+    // and stretch B is left with bare MFMAs
+    asm volatile("" : "+v"(pf0[0][0]), "+v"(pf0[0][1]), "+v"(pf0[1][0]), "+v"(pf0[1][1]));
+    // all eight V^T fragments (transposed reads), issued ahead of block 1's row maximum
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x4 vr[2][DB][2][2];
-    auto read_unit = [&](int kb, int slot) {
+    s16x4 vr[2][2][DB][2];                  // [key half][k-step][d-block][lo / hi]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
           const unsigned a = (unsigned)(uintptr_t)(v_lds + (kb * 32 + 16 * s) * ROWB + tr_off[d]);
-#if ICL_ATTN_ABL == 1
-          asm volatile("; no read %0 %1" : "=v"(vr[slot][d][s][0]) : "v"(a));
-          asm volatile("; no read %0 %1" : "=v"(vr[slot][d][s][1]) : "v"(a));
-#else
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vr[slot][d][s][0]) : "v"(a));
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[slot][d][s][1]) : "v"(a), "n"(8 * ROWB));
-#endif
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vr[kb][s][d][0]) : "v"(a));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[kb][s][d][1]) : "v"(a), "n"(8 * ROWB));
         }
-    };
-    read_unit(0, 0);
+    const bool nm1 = sm_head(1, s1, k0, maymask_c);
+    // ---- C: O0 += V^T P0  with  the exponentials of block 1 ----------------------------------------------------------------
+    bf16x8 vf[2][2][DB];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int slot = kb;
-      if (kb == 0) {
-        read_unit(1, 1);
-        asm volatile("s_waitcnt lgkmcnt(8)"
-                     : "+v"(vr[0][0][0][0]), "+v"(vr[0][0][0][1]), "+v"(vr[0][0][1][0]), "+v"(vr[0][0][1][1]),
-                       "+v"(vr[0][1][0][0]), "+v"(vr[0][1][0][1]), "+v"(vr[0][1][1][0]), "+v"(vr[0][1][1][1]));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(vr[1][0][0][0]), "+v"(vr[1][0][0][1]), "+v"(vr[1][0][1][0]), "+v"(vr[1][0][1][1]),
-                       "+v"(vr[1][1][0][0]), "+v"(vr[1][1][0][1]), "+v"(vr[1][1][1][0]), "+v"(vr[1][1][1][1]));
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (kb == 0 && s == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(vr[0][0][0][0]), "+v"(vr[0][0][0][1]), "+v"(vr[0][0][1][0]), "+v"(vr[0][0][1][1]));
+        if (kb == 0 && s == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vr[0][1][0][0]), "+v"(vr[0][1][0][1]), "+v"(vr[0][1][1][0]), "+v"(vr[0][1][1][1]));
+        if (kb == 1 && s == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vr[1][0][0][0]), "+v"(vr[1][0][0][1]), "+v"(vr[1][0][1][0]), "+v"(vr[1][0][1][1]));
+        if (kb == 1 && s == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[1][1][0][0]), "+v"(vr[1][1][0][1]), "+v"(vr[1][1][1][0]), "+v"(vr[1][1][1][1]));
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const s16x8 both = __builtin_shufflevector(vr[kb][s][d][0], vr[kb][s][d][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          vf[kb][s][d] = __builtin_bit_cast(bf16x8, both);
+          o_acc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb][s][d], pf0[kb][s], o_acc[0][d], 0, 0, 0);
+        }
       }
+    sm_tail(1, s1, nm1, pf1);
+    // ---- D: O1 += V^T P1 -------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          const s16x8 both = __builtin_shufflevector(vr[slot][d][s][0], vr[slot][d][s][1], 0, 1, 2, 3, 4, 5, 6, 7);
-#if ICL_ATTN_ABL == 2
-          o_acc[d][s] += (float)__builtin_bit_cast(bf16x8, both)[0] * (float)pf[kb][s][0];
-#else
-          o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf[kb][s], o_acc[d], 0, 0, 0);
-#endif
-        }
-    }
-  };
-
-  // ---- prologue: tiles 0..2 staged, 0 and 1 landed, S(0) computed ---------------------------------------------------------
-  stage_tile(0, 0);
-  stage_tile(min(1, n_tiles - 1), 1);
-  stage_tile(min(2, n_tiles - 1), 2);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  auto body = [&](const int t, f32x16 (&sc)[2], f32x16 (&sn)[2], auto maymask_c) {
-    const int nx1 = (cur + 1) & (NBUF - 1), nx3 = (cur + 3) & (NBUF - 1);
-#if ICL_ATTN_ABL != 4
-    stage_tile(min(t + 3, n_tiles - 1), nx3);
-#endif
-    const bool need_mask = softmax_head(sc, t * 64, maymask_c);
-    // one block from here on: 8 MFMAs of the NEXT tile's scores, this tile's exponentials, 8 MFMAs of P V
-    qk(lds + nx1 * BUF, sn);            // the last iteration recomputes the last tile's scores (its slot holds it again): unused
-    bf16x8 pf[2][2];
-#if ICL_ATTN_ABL == 3
-    for (int kb = 0; kb < 2; ++kb) for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (__bf16)sc[kb][r];   // (diagnostic) no exponentials
-#else
-    softmax_tail(sc, need_mask, pf);
-#endif
-    pv(lds + cur * BUF + 64 * ROWB, pf);
-#if ICL_ATTN_ABL != 4 && ICL_ATTN_ABL != 5
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t+2 (issued an iteration ago) has landed; t+3 stays in flight
+        for (int d = 0; d < DB; ++d)
+          o_acc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb][s][d], pf1[kb][s], o_acc[1][d], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's share of tile t+1 has landed; t+2 stays in flight
     __builtin_amdgcn_s_barrier();
-#endif
-    cur = nx1;
+    cur = cur + 1 == NBUF ? 0 : cur + 1;
   };
-  f32x16 sA[2], sB[2];
-  qk(lds, sA);
-  // interior tiles in pairs (the score buffers swap roles without copies), then the rest one at a time through the general
-  // body with an explicit copy
-  const int n_plain = min(n_tiles, CAUSAL ? min(kvlen, qw + 1) >> 6 : kvlen >> 6);
   int t = 0;
-  for (; t + 1 < n_plain; t += 2) {
-    body(t, sA, sB, std::false_type{});
-    body(t + 1, sB, sA, std::false_type{});
+  {
+    const int n_plain = min(n_tiles, CAUSAL ? min(kvlen, qw[0] + 1) >> 6 : kvlen >> 6);
+    for (; t < n_plain; ++t) tile(t, std::false_type{});
   }
-  for (; t < n_tiles; ++t) {
-    body(t, sA, sB, std::true_type{});
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) sA[kb] = sB[kb];
-  }
-
-  // ---- epilogue (as above); the last iterations staged (again) into ring slots it is about to reuse -------------------------
+  for (; t < n_tiles; ++t) tile(t, std::true_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+
+  // ---- epilogue (as above) -----------------------------------------------------------------------------------------------
+  float inv[QB];
+#pragma unroll
+  for (int qi = 0; qi < QB; ++qi) {
+    const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+    inv[qi] = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  }
   const bool rows16 = (((uintptr_t)p.O | (uintptr_t)(p.ldo * 2)) & 15) == 0;
   if (rows16) {
     constexpr int PITCH = D * 2 + 16;
     constexpr int LPR = D * 2 / 16, RPS = 64 / LPR;
-    char* stg = lds + wave * (32 * PITCH);
+    char* stg = lds + wave * (QB * 32 * PITCH);
 #pragma unroll
-    for (int d = 0; d < DB; ++d)
+    for (int qi = 0; qi < QB; ++qi)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = d * 32 + 8 * g + 4 * hh;
-        *(u32x2*)(stg + ql * PITCH + d0 * 2) = u32x2{pack_bf16x2(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv),
-                                                     pack_bf16x2(o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv)};
-      }
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          *(u32x2*)(stg + (qi * 32 + ql) * PITCH + d0 * 2) =
+              u32x2{pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                    pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+        }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 32 / RPS; ++it) {
+    for (int it = 0; it < QB * 32 / RPS; ++it) {
       const int row = it * RPS + lane / LPR, cc = lane % LPR;
-      const int q = qw + row;
+      const int q = qw[row >> 5] + (row & 31);
       const u32x4 v = *(const u32x4*)(stg + row * PITCH + cc * 16);
       if (q < len) *(u32x4*)(p.O + (int64_t)(row0 + q) * p.ldo + head * D + cc * 8) = v;
     }
     return;
   }
-  if (qpos < len) {
-    unsigned short* op = p.O + (int64_t)(row0 + qpos) * p.ldo + head * D;
 #pragma unroll
-    for (int d = 0; d < DB; ++d)
+  for (int qi = 0; qi < QB; ++qi) {
+    if (qpos[qi] < len) {
+      unsigned short* op = p.O + (int64_t)(row0 + qpos[qi]) * p.ldo + head * D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = d * 32 + 8 * g + 4 * hh;
-        *(u32x2*)(op + d0) = u32x2{pack_bf16x2(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv),
-                                   pack_bf16x2(o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv)};
-      }
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = d * 32 + 8 * g + 4 * hh;
+          *(u32x2*)(op + d0) = u32x2{pack_bf16x2(o_acc[qi][d][4 * g] * inv[qi], o_acc[qi][d][4 * g + 1] * inv[qi]),
+                                     pack_bf16x2(o_acc[qi][d][4 * g + 2] * inv[qi], o_acc[qi][d][4 * g + 3] * inv[qi])};
+        }
+    }
   }
 }
 
 template <int D>
 int launch_attn(const AttnParams& p, const icl_attn_args* a, hipStream_t stream) {
-  const int bq = 128;                                     // queries per workgroup
+  const int bq = (D == 64 && !a->rel_bias) ? 256 : 128;   // queries per workgroup
   dim3 grid(((a->max_seqlen + bq - 1) / bq) * a->n_heads * a->n_seqs, 1, 1);
   const bool bias = a->rel_bias != nullptr;
   if (D == 64 && !bias) {
-    if (a->causal) hipLaunchKernelGGL((attn_fwd_pipe64_kernel<true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((attn_fwd_pipe64_kernel<false>), grid, dim3(256), 0, stream, p);
+    if (a->causal) hipLaunchKernelGGL((attn_fwd_il64_kernel<true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_il64_kernel<false>), grid, dim3(256), 0, stream, p);
     ICL_CHECK_LAUNCH("icl_attn_fwd_bf16");
     return ICL_OK;
   }
@@ -890,7 +871,8 @@ extern "C" int icl_attn_fwd_bf16(const icl_attn_args* a, void* stream) {
   p.kv_seq_stride = a->kv_seq_stride; p.kv_head_stride = a->kv_head_stride;
   p.n_heads = a->n_heads;
   p.rel_span = a->rel_span;
-  p.n_qblocks = (a->max_seqlen + 127) / 128;
+  const int bq = (a->head_dim == 64 && !a->rel_bias) ? 256 : 128;
+  p.n_qblocks = (a->max_seqlen + bq - 1) / bq;
   p.scale_log2e = a->scale * LOG2E;
   return a->head_dim == 64 ? launch_attn<64>(p, a, (hipStream_t)stream) : launch_attn<128>(p, a, (hipStream_t)stream);
 }
