@@ -1,22 +1,22 @@
 // frontend.hip — audio front-ends of the ICL path on gfx950:
 //   K1  Whisper log-mel   (WhisperFeatureExtractor semantics; data/model_processors.py:641-645)
 //   K4  BEATs Kaldi fbank (torchaudio.compliance.kaldi.fbank semantics as used by BEATs.preprocess)
-// Both are tiny (≈1 GFLOP per 30 s clip) and are computed in f64 (direct DFT from an LDS twiddle
-// table: n_fft = 400 is not a power of two and MI355X has full-rate f64 vector FMA), so the result
-// is closer to the exact value than the reference's f32 FFT; outputs are f32.
-// Layout: one block = FR consecutive frames of one audio; frames are staged (windowed) in LDS, folded into
-// s[n] = x[n] + x[N-n], d[n] = x[n] - x[N-n], and every thread owns a PAIR of frequency bins (k, N/2 - k) for all
-// FR frames (the frame sample is an LDS broadcast, the twiddle a per-lane LDS read shared by both bins): a quarter of
-// the plain DFT's FMAs and LDS reads.  Loads of the waveform are coalesced; nothing is re-read from HBM.
+// Both are tiny (≈1 GFLOP per 30 s clip) and are computed in f64 (direct DFT from an LDS twiddle table: n_fft = 400 is not a
+// power of two), so the result is closer to the exact value than the reference's f32 FFT; outputs are f32.
+// Layout: one block walks groups of 16 consecutive frames of one audio.  The samples the 16 frames cover are staged once in
+// LDS (f32, exact); the transform uses the real-input fold s[n] = x[n] + x[N-n], d[n] = x[n] - x[N-n] and the bin pairing
+// (k, N/2 - k) — a quarter of the plain DFT's FMAs — and runs as four small GEMMs on the f64 matrix pipe
+// (dft_power_mfma below; round 1 ran the same sums on the vector pipe, bound by one LDS read per FMA pair: 3.7 / 4.6 ms for
+// 128 clips against 1.5 / 2.8 ms now).  Loads of the waveform are coalesced; nothing is re-read from HBM.
 #include "common.h"
 
 namespace {
 
-constexpr int FR = 8;            // frames per block
 constexpr int WLEN = 400;        // window length (both front-ends)
 constexpr int HOP = 160;
 constexpr int WH_NFFT = 400, WH_BINS = 201, WH_FRAMES = 3000, WH_SAMPLES = 480000;
 constexpr int FB_NFFT = 512, FB_BINS = 256, FB_MEL = 128;  // Nyquist bin has a zero mel column
+constexpr int WH_GROUPS = 4, FB_GROUPS = 4;     // groups of 16 frames per block (Whisper: 3000 / 16 = 188 groups = 47 blocks x 4 per clip)
 
 __device__ __forceinline__ int float_to_ordered(float f) {
   const int i = __float_as_int(f);
@@ -24,93 +24,26 @@ __device__ __forceinline__ int float_to_ordered(float f) {
 }
 __device__ __forceinline__ float ordered_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 
-// power[f][bin] = |sum_n x[f][n] * exp(-2 pi i bin n / NFFT)|^2, one bin per thread, x real with x[n] = 0 for n >= WLEN.
-// Real-input symmetry: cos(2 pi k (N-n)/N) = cos(2 pi k n/N) and sin(...(N-n)) = -sin(...n), so with
-//   s[n] = x[n] + x[N-n],  d[n] = x[n] - x[N-n]   (n = 1 .. N/2-1, folded IN PLACE into the frame rows beforehand)
-//   Re X[k] = x[0] + (-1)^k x[N/2] + sum_n s[n] cos(2 pi k n/N),   Im X[k] = -sum_n d[n] sin(2 pi k n/N)
-// the loop runs over N/2-1 sample pairs with one twiddle read and 2 FMAs per frame each: half the FMAs and half the LDS
-// twiddle traffic of the plain sum.  FSTR = row pitch of the frame array (>= NFFT so that n and N-n both have a slot).
-template <int NFFT, int FSTR>
-__device__ __forceinline__ void fold_frames(double* frames) {
-  constexpr int HALF = NFFT / 2;
-  for (int i = threadIdx.x; i < FR * (HALF - 1); i += blockDim.x) {
-    const int f = i / (HALF - 1), n = 1 + i - f * (HALF - 1);
-    if (NFFT - n < WLEN) {          // the partner sample exists (always for NFFT = WLEN; n >= NFFT - WLEN + 1 when zero-padded)
-      double* row = frames + f * FSTR;
-      const double a = row[n], b = row[NFFT - n];
-      row[n] = a + b;
-      row[NFFT - n] = a - b;
-    }
-  }
-}
-// Bin symmetry on top of it: theta_n(N/2 - k) = pi n - theta_n(k), so cos -> (-1)^n cos and sin -> -(-1)^n sin.  With the
-// sums split by the parity of n,  E = sum_even s[n] cos, O = sum_odd s[n] cos, Ei = sum_even d[n] sin, Oi = sum_odd d[n] sin:
-//   X[k]       = (x0 + (-1)^k xh + E + O) - i (Ei + Oi)
-//   X[N/2 - k] = (x0 + (-1)^(N/2-k) xh + E - O) + i (Ei - Oi)
-// one thread produces BOTH bins from one pass over the sample pairs: a quarter of the plain sum's FMAs and LDS reads.
-template <int NFFT, int NB, int FSTR>
-__device__ __forceinline__ void dft_power(const double* frames, const double* tw, double* power) {
-  constexpr int HALF = NFFT / 2, QUART = NFFT / 4;
-  static_assert(NFFT % 4 == 0, "bin pairing needs NFFT % 4 == 0");
-  const int bin = threadIdx.x;                 // 0 .. NFFT/4; partner bin = NFFT/2 - bin
-  if (bin <= QUART) {
-    double e[FR], o[FR], ei[FR], oi[FR];
-#pragma unroll
-    for (int f = 0; f < FR; ++f) e[f] = o[f] = ei[f] = oi[f] = 0.0;
-    int idx = bin;
-    for (int n = 1; n < HALF; n += 2) {        // n odd, then n + 1 even
-      {
-        const double c = tw[2 * idx], s = tw[2 * idx + 1];
-        const int nd = (NFFT - n < WLEN) ? NFFT - n : n;
-#pragma unroll
-        for (int f = 0; f < FR; ++f) {
-          o[f] += frames[f * FSTR + n] * c;
-          oi[f] += frames[f * FSTR + nd] * s;
-        }
-        idx += bin;
-        if (idx >= NFFT) idx -= NFFT;
-      }
-      if (n + 1 < HALF) {
-        const double c = tw[2 * idx], s = tw[2 * idx + 1];
-        const int m = n + 1, nd = (NFFT - m < WLEN) ? NFFT - m : m;
-#pragma unroll
-        for (int f = 0; f < FR; ++f) {
-          e[f] += frames[f * FSTR + m] * c;
-          ei[f] += frames[f * FSTR + nd] * s;
-        }
-        idx += bin;
-        if (idx >= NFFT) idx -= NFFT;
-      }
-    }
-    const int pb = HALF - bin;                 // partner bin
-    const double sg = (bin & 1) ? -1.0 : 1.0, sp = (pb & 1) ? -1.0 : 1.0;
-#pragma unroll
-    for (int f = 0; f < FR; ++f) {
-      const double x0 = frames[f * FSTR], xh = HALF < WLEN ? frames[f * FSTR + HALF] : 0.0;
-      const double re = x0 + sg * xh + e[f] + o[f], im = ei[f] + oi[f];
-      power[f * NB + bin] = re * re + im * im;
-      if (pb < NB && pb != bin) {
-        const double re2 = x0 + sp * xh + e[f] - o[f], im2 = ei[f] - oi[f];
-        power[f * NB + pb] = re2 * re2 + im2 * im2;
-      }
-    }
-  }
-}
-
 // [lo, hi) of the non-zero taps of every (triangular, contiguous) mel filter, found once per block: the projection then
-// walks 5-30 bins per filter instead of all of them
+// walks 5-30 bins per filter instead of all of them.  The whole block scans the filter matrix with independent, coalesced
+// loads and LDS atomics on the few non-zeros (a thread walking one row alone is a chain of L2 round trips: 200-256 of them
+// per block used to cost more than the transform).
 __device__ __forceinline__ void mel_ranges(const double* mel, int n_mel, int row_ld, int n_bins, int* lo, int* hi) {
   for (int m = threadIdx.x; m < n_mel; m += blockDim.x) {
-    const double* mf = mel + (int64_t)m * row_ld;
-    int a = n_bins, b = 0;
-    for (int k = 0; k < n_bins; ++k)
-      if (mf[k] != 0.0) {
-        a = min(a, k);
-        b = k + 1;
-      }
-    lo[m] = min(a, b);
-    hi[m] = b;
+    lo[m] = n_bins;
+    hi[m] = 0;
   }
+  __syncthreads();
+  const int total = n_mel * n_bins;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int m = i / n_bins, k = i - m * n_bins;
+    if (mel[(int64_t)m * row_ld + k] != 0.0) {
+      atomicMin(&lo[m], k);
+      atomicMax(&hi[m], k + 1);
+    }
+  }
+  __syncthreads();
+  for (int m = threadIdx.x; m < n_mel; m += blockDim.x) lo[m] = min(lo[m], hi[m]);
 }
 
 template <int NFFT>
@@ -123,45 +56,164 @@ __device__ __forceinline__ void fill_twiddles(double* tw) {
   }
 }
 
+// The non-zero taps of all filters packed back to back in LDS (a bin feeds at most two triangular filters, so about 2 x bins
+// doubles), offset table moff[]: the projection's inner loop then reads LDS instead of walking a global row, one dependent L2
+// load per tap.  Filter banks whose taps do not fit MEL_TAPS stay in global memory (moff[0] = -1).
+constexpr int MEL_TAPS = 640;
+__device__ __forceinline__ void mel_pack(const double* mel, int n_mel, int row_ld, const int* lo, const int* hi, int* moff,
+                                         double* taps) {
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int m = 0; m < n_mel; ++m) {
+      moff[m] = tot;
+      tot += hi[m] - lo[m];
+    }
+    if (tot > MEL_TAPS) moff[0] = -1;
+  }
+  __syncthreads();
+  if (moff[0] < 0) return;
+  for (int m = threadIdx.x; m < n_mel; m += blockDim.x) {
+    const double* mf = mel + (int64_t)m * row_ld;
+    for (int b = lo[m]; b < hi[m]; ++b) taps[moff[m] + b - lo[m]] = mf[b];
+  }
+}
+__device__ __forceinline__ double mel_dot(const double* mel, int row_ld, int m, const int* lo, const int* hi, const int* moff,
+                                          const double* taps, const double* pw) {
+  double acc = 0.0;
+  if (moff[0] >= 0) {
+    const double* tp = taps + moff[m] - lo[m];
+    for (int b = lo[m]; b < hi[m]; ++b) acc += tp[b] * pw[b];
+  } else {
+    const double* mf = mel + (int64_t)m * row_ld;
+    for (int b = lo[m]; b < hi[m]; ++b) acc += mf[b] * pw[b];
+  }
+  return acc;
+}
+
+// ---- DFT power of MF = 16 frames on the f64 matrix pipe ----------------------------------------------------------------
+// The same folded sums as dft_power() written as four small GEMMs, frames x samples x bins, on v_mfma_f64_16x16x4_f64:
+//   E = S_even C_even,  O = S_odd C_odd,  Ei = D_even Sn_even,  Oi = D_odd Sn_odd      (bins k = 0 .. N/4)
+//   X[k] = (E + O) - i (Ei + Oi),   X[N/2 - k] = (E - O) + i (Ei - Oi)
+// with s[n] = x[n] + x[N-n], d[n] = x[n] - x[N-n] for 0 < n < N/2, s[0] = x[0], s[N/2] = x[N/2], d[0] = d[N/2] = 0 (so the
+// DC and Nyquist samples ride in the even sum).  The vector form above reads LDS once per FMA pair and is bound by that
+// (11-15 % of the f64 FMA rate); here one 8-byte operand per lane feeds 1024 FMAs.  Operand maps (guide, "MFMA layouts"):
+// A[frame = lane & 15][sample slot = lane >> 4], B[slot = lane >> 4][bin = lane & 15], C/D col = lane & 15 (bin),
+// row = (lane >> 4) + 4 r (frame).  A lane builds its A operands itself from the staged samples through `xw(frame, n)`
+// (windowed sample in f64, 0 outside the window), so no folded copy of the frames lives in LDS; twiddles start from the
+// cos/sin table and advance by rotation.  Wave w owns bin tiles w*NT .. w*NT + NT-1.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int MF = 16;
+template <int NFFT, int NB, int NT, class XW>
+__device__ __forceinline__ void dft_power_mfma(const double* tw, double* power, XW xw) {
+  constexpr int HALF = NFFT / 2, QUART = NFFT / 4;
+  constexpr int KE = (QUART + 1 + 3) / 4;       // K-steps: even n = 0, 2 .. N/2 (N/4 + 1 samples); odd n = 1, 3 .. N/2 - 1 fit in them
+  static_assert(NFFT % 8 == 0, "even / odd split of the folded samples");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = lane & 15, q = lane >> 4;
+  f64x4 E[NT], O[NT], Ei[NT], Oi[NT];
+  // twiddles of this lane's bin for its current even / odd sample, advanced by ROTATION (angle 2 pi 8k / N per K-step, four
+  // f64 FMAs each) instead of a table read per step: lanes of consecutive bins hit the table with stride n — bank conflicts
+  // that made the LDS, not the matrix pipe, the limit.  33 rotations add ~4e-15 of relative error (outputs are f32).
+  double ce[NT], sne[NT], co[NT], sno[NT], cd[NT], sd[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    E[t] = O[t] = Ei[t] = Oi[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int k = min((wave * NT + t) * 16 + f, QUART);      // padding bins repeat bin N/4; their results are not stored
+    const int ie = (k * (2 * q)) % NFFT, io = (k * (2 * q + 1)) % NFFT, inc = (k * 8) % NFFT;
+    ce[t] = tw[2 * ie];
+    sne[t] = tw[2 * ie + 1];
+    co[t] = tw[2 * io];
+    sno[t] = tw[2 * io + 1];
+    cd[t] = tw[2 * inc];
+    sd[t] = tw[2 * inc + 1];
+  }
+  for (int j = 0; j < KE; ++j) {
+    // branch-free (selects on clamped indices): q differs between lanes, a branch here is a divergent one around LDS reads
+    const int ne = 2 * (4 * j + q), no = ne + 1;
+    const int nec = min(ne, HALF), noc = min(no, HALF - 1);
+    const double ae = xw(f, nec), be = xw(f, nec == 0 ? 0 : NFFT - nec);
+    const double ao = xw(f, noc), bo = xw(f, NFFT - noc);
+    const bool mid = ne > 0 && ne < HALF, edge = ne == 0 || ne == HALF, odd = no < HALF;
+    const double se = mid ? ae + be : (edge ? ae : 0.0), de = mid ? ae - be : 0.0;
+    const double so = odd ? ao + bo : 0.0, dd = odd ? ao - bo : 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      E[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(se, ce[t], E[t], 0, 0, 0);
+      Ei[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(de, sne[t], Ei[t], 0, 0, 0);
+      O[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(so, co[t], O[t], 0, 0, 0);
+      Oi[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(dd, sno[t], Oi[t], 0, 0, 0);
+      const double c1 = ce[t] * cd[t] - sne[t] * sd[t], s1 = sne[t] * cd[t] + ce[t] * sd[t];
+      const double c2 = co[t] * cd[t] - sno[t] * sd[t], s2 = sno[t] * cd[t] + co[t] * sd[t];
+      ce[t] = c1;
+      sne[t] = s1;
+      co[t] = c2;
+      sno[t] = s2;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int k = (wave * NT + t) * 16 + f;
+    if (k > QUART) continue;
+    const int pb = HALF - k;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int fr = q + 4 * r;
+      const double re = E[t][r] + O[t][r], im = Ei[t][r] + Oi[t][r];
+      power[fr * NB + k] = re * re + im * im;
+      if (pb < NB && pb != k) {
+        const double re2 = E[t][r] - O[t][r], im2 = Ei[t][r] - Oi[t][r];
+        power[fr * NB + pb] = re2 * re2 + im2 * im2;
+      }
+    }
+  }
+}
+
+// (launch bounds with a minimum of 2 waves per SIMD on both transform kernels: with the whole 512-register file on offer hipcc
+// puts the MFMA accumulators in AGPRs but carries them through the loop in VGPRs — 96 copies in and 96 out per K-step)
 // ---- K1 stage 1: STFT power -> mel -> log10, per-audio running max -----------------------------------
-__global__ __launch_bounds__(256) void whisper_logmel_kernel(const float* wav, int64_t wav_ld, const int* wav_lens,
+__global__ __launch_bounds__(256, 2) void whisper_logmel_kernel(const float* wav, int64_t wav_ld, const int* wav_lens,
                                                               const double* mel, int n_mel, float* raw,
                                                               int* gmax) {
-  __shared__ double frames[FR * WLEN];
+  constexpr int SPAN = (MF - 1) * HOP + WLEN;        // samples the block's MF frames cover (hop 160, window 400)
+  __shared__ float span[SPAN];
   __shared__ double tw[2 * WH_NFFT];
-  __shared__ double power[FR * WH_BINS];
-  __shared__ int mlo[128], mhi[128];
-  const int a = blockIdx.y, f0 = blockIdx.x * FR;
+  __shared__ double power[MF * WH_BINS];
+  __shared__ double taps[MEL_TAPS];
+  __shared__ int mlo[128], mhi[128], moff[128];
+  const int a = blockIdx.y;
   const float* w = wav + (int64_t)a * wav_ld;
   const int L = min(wav_lens[a], WH_SAMPLES);
+  // the twiddle table and the mel tap ranges are per-block set-up (400 f64 sincospi, a scan of the 80 x 201 filter matrix):
+  // one block walks WH_GROUPS groups of MF frames so that it is paid once per WH_GROUPS * MF frames
   fill_twiddles<WH_NFFT>(tw);
   mel_ranges(mel, n_mel, WH_BINS, WH_BINS, mlo, mhi);
   __syncthreads();
-  // centre frames over the zero-padded 480000-sample signal with reflect padding of n_fft/2
-  for (int i = threadIdx.x; i < FR * WLEN; i += blockDim.x) {
-    const int f = i / WLEN, n = i - f * WLEN;
-    int j = (f0 + f) * HOP + n - WH_NFFT / 2;
-    if (j < 0) j = -j;
-    if (j >= WH_SAMPLES) j = 2 * (WH_SAMPLES - 1) - j;
-    const double x = (j < L) ? (double)w[j] : 0.0;
-    frames[i] = x * (0.5 - 0.5 * tw[2 * n]);  // periodic Hann: cos(2 pi n / 400) is the twiddle
-  }
-  __syncthreads();
-  fold_frames<WH_NFFT, WLEN>(frames);
-  __syncthreads();
-  dft_power<WH_NFFT, WH_BINS, WLEN>(frames, tw, power);
-  __syncthreads();
+  mel_pack(mel, n_mel, WH_BINS, mlo, mhi, moff, taps);
   float local_max = -INFINITY;
-  for (int o = threadIdx.x; o < n_mel * FR; o += blockDim.x) {
-    const int m = o / FR, f = o - m * FR;
-    if (f0 + f >= WH_FRAMES) continue;
-    const double* mf = mel + (int64_t)m * WH_BINS;
-    const double* pw = power + f * WH_BINS;
-    double acc = 0.0;
-    for (int b = mlo[m]; b < mhi[m]; ++b) acc += mf[b] * pw[b];
-    const float lv = (float)log10(fmax(acc, 1e-10));
-    raw[((int64_t)a * n_mel + m) * WH_FRAMES + f0 + f] = lv;
-    local_max = fmaxf(local_max, lv);
+  for (int g = 0; g < WH_GROUPS; ++g) {
+    const int f0 = (blockIdx.x * WH_GROUPS + g) * MF;
+    if (f0 >= WH_FRAMES) break;
+    __syncthreads();                       // set-up visible (g = 0) / the previous group's span and power are consumed
+    // centre frames over the zero-padded 480000-sample signal with reflect padding of n_fft/2: sample i of the span is signal
+    // index f0 * hop - 200 + i (f32 staging is exact; the arithmetic is f64)
+    for (int i = threadIdx.x; i < SPAN; i += blockDim.x) {
+      int j = f0 * HOP + i - WH_NFFT / 2;
+      if (j < 0) j = -j;
+      if (j >= WH_SAMPLES) j = 2 * (WH_SAMPLES - 1) - j;
+      span[i] = (j >= 0 && j < L) ? w[j] : 0.f;
+    }
+    __syncthreads();
+    // periodic Hann: cos(2 pi n / 400) is the twiddle
+    dft_power_mfma<WH_NFFT, WH_BINS, 2>(tw, power, [&](int f, int n) { return (double)span[f * HOP + n] * (0.5 - 0.5 * tw[2 * n]); });
+    __syncthreads();
+    for (int o = threadIdx.x; o < n_mel * MF; o += blockDim.x) {
+      const int m = o / MF, f = o - m * MF;
+      if (f0 + f >= WH_FRAMES) continue;
+      const double acc = mel_dot(mel, WH_BINS, m, mlo, mhi, moff, taps, power + f * WH_BINS);
+      const float lv = (float)log10(fmax(acc, 1e-10));
+      raw[((int64_t)a * n_mel + m) * WH_FRAMES + f0 + f] = lv;
+      local_max = fmaxf(local_max, lv);
+    }
   }
   local_max = wave_reduce_max(local_max);
   if ((threadIdx.x & 63) == 0 && local_max > -INFINITY) atomicMax(gmax + a, float_to_ordered(local_max));
@@ -206,74 +258,72 @@ __global__ __launch_bounds__(256) void whisper_logmel_finish_kernel(const float*
 }
 
 // ---- K4: Kaldi fbank ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kaldi_fbank_kernel(const float* wav, int64_t wav_ld, const int* wav_lens,
+__global__ __launch_bounds__(192, 2) void kaldi_fbank_kernel(const float* wav, int64_t wav_ld, const int* wav_lens,
                                                            const double* mel, int max_frames, float mean,
                                                            float stdv, float* out) {
-  __shared__ double frames[FR * WLEN];
+  // 3 waves x 3 bin tiles of 16 = the 129 bin pairs of the 512-point transform; MF = 16 frames per group
+  constexpr int SPAN = (MF - 1) * HOP + WLEN;
+  __shared__ float span[SPAN];               // raw samples of the group's frames (snip_edges framing: frame f starts at f * hop)
   __shared__ double tw[2 * FB_NFFT];
-  __shared__ double power[FR * FB_BINS];
-  __shared__ double fmean[FR];
-  __shared__ int mlo[FB_MEL], mhi[FB_MEL];
-  const int a = blockIdx.y, f0 = blockIdx.x * FR;
+  __shared__ double power[MF * FB_BINS];
+  __shared__ double povey[WLEN];
+  __shared__ double fmean[MF];
+  __shared__ double taps[MEL_TAPS];
+  __shared__ int mlo[FB_MEL], mhi[FB_MEL], moff[FB_MEL];
+  const int a = blockIdx.y;
   const float* w = wav + (int64_t)a * wav_ld;
   const int L = wav_lens[a];
   const int n_frames = L >= WLEN ? 1 + (L - WLEN) / HOP : 0;
-  if (f0 >= min(n_frames, max_frames)) return;
+  const int f_end = min(n_frames, max_frames);
+  if (blockIdx.x * FB_GROUPS * MF >= f_end) return;
+  // per-block set-up, paid once per FB_GROUPS * MF frames: twiddles, povey window, mel tap ranges + packed taps
   fill_twiddles<FB_NFFT>(tw);
+  for (int n = threadIdx.x; n < WLEN; n += blockDim.x)
+    povey[n] = pow(0.5 - 0.5 * cospi(2.0 * (double)n / (double)(WLEN - 1)), 0.85);
   mel_ranges(mel, FB_MEL, FB_BINS + 1, FB_BINS, mlo, mhi);
-  // raw frames (x * 2^15), snip_edges framing
-  for (int i = threadIdx.x; i < FR * WLEN; i += blockDim.x) {
-    const int f = i / WLEN, n = i - f * WLEN;
-    const int fr = min(f0 + f, n_frames - 1);
-    frames[i] = (double)w[(int64_t)fr * HOP + n] * 32768.0;
-  }
   __syncthreads();
-  {  // DC offset: 32 threads per frame
-    const int f = threadIdx.x >> 5, l = threadIdx.x & 31;
-    double s = 0.0;
-    for (int n = l; n < WLEN; n += 32) s += frames[f * WLEN + n];
+  mel_pack(mel, FB_MEL, FB_BINS + 1, mlo, mhi, moff, taps);
+  for (int g = 0; g < FB_GROUPS; ++g) {
+    const int f0 = (blockIdx.x * FB_GROUPS + g) * MF;
+    if (f0 >= f_end) break;                  // block-uniform
+    __syncthreads();
+    // frames past the last one repeat it (their rows are not stored): frame f reads the span at (min(f0 + f, n_frames - 1) - f0) * hop
+    const int last = n_frames - 1 - f0;      // >= 0
+    for (int i = threadIdx.x; i < SPAN; i += blockDim.x) {
+      const int64_t j = (int64_t)f0 * HOP + i;
+      span[i] = j < L ? w[j] : 0.f;
+    }
+    __syncthreads();
+    {  // DC offset of x * 2^15: 8 threads per frame, fixed order
+      const int f = threadIdx.x >> 3, l = threadIdx.x & 7;
+      if (f < MF) {
+        const int base = min(f, last) * HOP;
+        double sacc = 0.0;
+        for (int n = l; n < WLEN; n += 8) sacc += (double)span[base + n] * 32768.0;
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (l == 0) fmean[f] = s / (double)WLEN;
-  }
-  __syncthreads();
-  // pre-emphasis needs the un-emphasised neighbour: compute into registers, then write back
-  {
-    constexpr int NV = (FR * WLEN + 255) / 256;
-    double vals[NV];
-#pragma unroll
-    for (int c = 0; c < NV; ++c) {
-      const int i = threadIdx.x + c * 256;
-      vals[c] = 0.0;
-      if (i < FR * WLEN) {
-        const int f = i / WLEN, n = i - f * WLEN;
-        const double cur = frames[i] - fmean[f];
-        const double prev = frames[n > 0 ? i - 1 : i] - fmean[f];
-        const double win = pow(0.5 - 0.5 * cospi(2.0 * (double)n / (double)(WLEN - 1)), 0.85);  // povey
-        vals[c] = (cur - 0.97 * prev) * win;
+        for (int o = 4; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+        if (l == 0) fmean[f] = sacc / (double)WLEN;
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NV; ++c) {
-      const int i = threadIdx.x + c * 256;
-      if (i < FR * WLEN) frames[i] = vals[c];
+    // windowed sample: remove the DC offset, pre-emphasise against the un-emphasised neighbour (sample 0 against itself), povey
+    dft_power_mfma<FB_NFFT, FB_BINS, 3>(tw, power, [&](int f, int n) -> double {
+      const int nc = min(n, WLEN - 1);       // (the 512-point transform's samples 400 .. 511 are zero padding)
+      const int base = min(f, last) * HOP;
+      const double mu = fmean[f];
+      const double cur = (double)span[base + nc] * 32768.0 - mu;
+      const double prev = (double)span[base + max(nc - 1, 0)] * 32768.0 - mu;
+      const double v = (cur - 0.97 * prev) * povey[nc];
+      return n < WLEN ? v : 0.0;
+    });
+    __syncthreads();
+    for (int o = threadIdx.x; o < FB_MEL * MF; o += blockDim.x) {
+      const int f = o / FB_MEL, m = o - f * FB_MEL;
+      if (f0 + f >= f_end) continue;
+      const double acc = mel_dot(mel, FB_BINS + 1, m, mlo, mhi, moff, taps, power + f * FB_BINS);
+      const double lv = log(fmax(acc, 1.1920928955078125e-07));
+      out[((int64_t)a * max_frames + f0 + f) * FB_MEL + m] = (float)((lv - (double)mean) / (2.0 * (double)stdv));
     }
-  }
-  __syncthreads();
-  fold_frames<FB_NFFT, WLEN>(frames);
-  __syncthreads();
-  dft_power<FB_NFFT, FB_BINS, WLEN>(frames, tw, power);
-  __syncthreads();
-  for (int o = threadIdx.x; o < FB_MEL * FR; o += blockDim.x) {
-    const int f = o / FB_MEL, m = o - f * FB_MEL;
-    if (f0 + f >= n_frames || f0 + f >= max_frames) continue;
-    const double* mf = mel + (int64_t)m * (FB_BINS + 1);
-    const double* pw = power + f * FB_BINS;
-    double acc = 0.0;
-    for (int b = mlo[m]; b < mhi[m]; ++b) acc += mf[b] * pw[b];
-    const double lv = log(fmax(acc, 1.1920928955078125e-07));
-    out[((int64_t)a * max_frames + f0 + f) * FB_MEL + m] = (float)((lv - (double)mean) / (2.0 * (double)stdv));
   }
 }
 
@@ -294,7 +344,7 @@ extern "C" int icl_logmel_whisper(const float* wav, int64_t wav_ld, const int32_
     icl_set_error("icl_logmel_whisper: memset failed: %s", hipGetErrorString(e));
     return ICL_ELAUNCH;
   }
-  hipLaunchKernelGGL(whisper_logmel_kernel, dim3((WH_FRAMES + FR - 1) / FR, n_audio), dim3(256), 0, stream, wav,
+  hipLaunchKernelGGL(whisper_logmel_kernel, dim3((WH_FRAMES + MF * WH_GROUPS - 1) / (MF * WH_GROUPS), n_audio), dim3(256), 0, stream, wav,
                      wav_ld, wav_lens, mel_filters, n_mel, raw, gmax);
   ICL_CHECK_LAUNCH("icl_logmel_whisper(stft)");
   hipLaunchKernelGGL(whisper_logmel_finish_kernel, dim3((WH_FRAMES + 63) / 64, n_audio), dim3(256), 0, stream,
@@ -320,7 +370,7 @@ extern "C" int icl_fbank_kaldi(const float* wav, int64_t wav_ld, const int32_t* 
   ICL_CHECK_ARG(wav && wav_lens && mel_banks && fbank, "icl_fbank_kaldi: NULL pointer");
   ICL_CHECK_ARG(n_audio > 0 && n_audio <= 65535 && max_frames > 0, "icl_fbank_kaldi: bad sizes");
   ICL_CHECK_ARG(stdv > 0.f, "icl_fbank_kaldi: std must be > 0");
-  hipLaunchKernelGGL(kaldi_fbank_kernel, dim3((max_frames + FR - 1) / FR, n_audio), dim3(256), 0,
+  hipLaunchKernelGGL(kaldi_fbank_kernel, dim3((max_frames + MF * FB_GROUPS - 1) / (MF * FB_GROUPS), n_audio), dim3(192), 0,
                      (hipStream_t)stream, wav, wav_ld, wav_lens, mel_banks, max_frames, mean, stdv, fbank);
   ICL_CHECK_LAUNCH("icl_fbank_kaldi");
   return ICL_OK;
