@@ -95,15 +95,17 @@ __device__ __forceinline__ double mel_dot(const double* mel, int row_ld, int m, 
 //   E = S_even C_even,  O = S_odd C_odd,  Ei = D_even Sn_even,  Oi = D_odd Sn_odd      (bins k = 0 .. N/4)
 //   X[k] = (E + O) - i (Ei + Oi),   X[N/2 - k] = (E - O) + i (Ei - Oi)
 // with s[n] = x[n] + x[N-n], d[n] = x[n] - x[N-n] for 0 < n < N/2, s[0] = x[0], s[N/2] = x[N/2], d[0] = d[N/2] = 0 (so the
-// DC and Nyquist samples ride in the even sum).  The vector form above reads LDS once per FMA pair and is bound by that
-// (11-15 % of the f64 FMA rate); here one 8-byte operand per lane feeds 1024 FMAs.  Operand maps (guide, "MFMA layouts"):
+// DC and Nyquist samples ride in the even sum).  Round 1's vector form read LDS once per FMA pair and was bound by that
+// (11-15 % of the f64 FMA rate); here one 8-byte operand per lane feeds 1024 FMAs and the kernels are bound by the matrix
+// pipe itself: v_mfma_f64_16x16x4_f64 measures ~128 cycles per instruction in these loops (16 FLOP/clk/SIMD, half the f64
+// VECTOR rate), so a register-blocked vector kernel could in principle go further.  Operand maps (guide, "MFMA layouts"):
 // A[frame = lane & 15][sample slot = lane >> 4], B[slot = lane >> 4][bin = lane & 15], C/D col = lane & 15 (bin),
 // row = (lane >> 4) + 4 r (frame).  A lane builds its A operands itself from the staged samples through `xw(frame, n)`
 // (windowed sample in f64, 0 outside the window), so no folded copy of the frames lives in LDS; twiddles start from the
 // cos/sin table and advance by rotation.  Wave w owns bin tiles w*NT .. w*NT + NT-1.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int MF = 16;
-template <int NFFT, int NB, int NT, class XW>
+template <int NFFT, int NB, int NT, bool POWER_ALIASES_FRAMES = false, class XW>
 __device__ __forceinline__ void dft_power_mfma(const double* tw, double* power, XW xw) {
   constexpr int HALF = NFFT / 2, QUART = NFFT / 4;
   constexpr int KE = (QUART + 1 + 3) / 4;       // K-steps: even n = 0, 2 .. N/2 (N/4 + 1 samples); odd n = 1, 3 .. N/2 - 1 fit in them
@@ -150,6 +152,7 @@ __device__ __forceinline__ void dft_power_mfma(const double* tw, double* power, 
       sno[t] = s2;
     }
   }
+  if (POWER_ALIASES_FRAMES) __syncthreads();    // every wave is done reading the frames `power` is about to overwrite
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int k = (wave * NT + t) * 16 + f;
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void whisper_logmel_kernel(const float* wav
     }
     __syncthreads();
     // periodic Hann: cos(2 pi n / 400) is the twiddle
-    dft_power_mfma<WH_NFFT, WH_BINS, 2>(tw, power, [&](int f, int n) { return (double)span[f * HOP + n] * (0.5 - 0.5 * tw[2 * n]); });
+    dft_power_mfma<WH_NFFT, WH_BINS, 2, false>(tw, power, [&](int f, int n) { return (double)span[f * HOP + n] * (0.5 - 0.5 * tw[2 * n]); });
     __syncthreads();
     for (int o = threadIdx.x; o < n_mel * MF; o += blockDim.x) {
       const int m = o / MF, f = o - m * MF;
@@ -259,17 +262,19 @@ __global__ __launch_bounds__(256) void whisper_logmel_finish_kernel(const float*
 
 // ---- K4: Kaldi fbank ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(192, 2) void kaldi_fbank_kernel(const float* wav, int64_t wav_ld, const int* wav_lens,
-                                                           const double* mel, int max_frames, float mean,
-                                                           float stdv, float* out) {
+                                                              const double* mel, int max_frames, float mean,
+                                                              float stdv, float* out) {
   // 3 waves x 3 bin tiles of 16 = the 129 bin pairs of the 512-point transform; MF = 16 frames per group
-  constexpr int SPAN = (MF - 1) * HOP + WLEN;
-  __shared__ float span[SPAN];               // raw samples of the group's frames (snip_edges framing: frame f starts at f * hop)
+  constexpr int XP = WLEN + 1;               // row pitch of the windowed frames (odd: the 16 frames of an A operand spread over the banks)
+  __shared__ double big[MF * XP];            // windowed frames during the transform, then (behind a barrier) the power spectrum
   __shared__ double tw[2 * FB_NFFT];
-  __shared__ double power[MF * FB_BINS];
   __shared__ double povey[WLEN];
   __shared__ double fmean[MF];
   __shared__ double taps[MEL_TAPS];
   __shared__ int mlo[FB_MEL], mhi[FB_MEL], moff[FB_MEL];
+  static_assert(MF * XP >= MF * FB_BINS, "the power spectrum reuses the frame buffer");
+  double* xwin = big;
+  double* power = big;
   const int a = blockIdx.y;
   const float* w = wav + (int64_t)a * wav_ld;
   const int L = wav_lens[a];
@@ -286,34 +291,34 @@ __global__ __launch_bounds__(192, 2) void kaldi_fbank_kernel(const float* wav, i
   for (int g = 0; g < FB_GROUPS; ++g) {
     const int f0 = (blockIdx.x * FB_GROUPS + g) * MF;
     if (f0 >= f_end) break;                  // block-uniform
-    __syncthreads();
-    // frames past the last one repeat it (their rows are not stored): frame f reads the span at (min(f0 + f, n_frames - 1) - f0) * hop
-    const int last = n_frames - 1 - f0;      // >= 0
-    for (int i = threadIdx.x; i < SPAN; i += blockDim.x) {
-      const int64_t j = (int64_t)f0 * HOP + i;
-      span[i] = j < L ? w[j] : 0.f;
-    }
-    __syncthreads();
+    __syncthreads();                         // set-up visible / the previous group's power spectrum is consumed
+    // snip_edges framing: frame f starts at sample f * hop; frames past the last one repeat it (their rows are not stored)
     {  // DC offset of x * 2^15: 8 threads per frame, fixed order
       const int f = threadIdx.x >> 3, l = threadIdx.x & 7;
       if (f < MF) {
-        const int base = min(f, last) * HOP;
+        const float* fw = w + (int64_t)min(f0 + f, n_frames - 1) * HOP;
         double sacc = 0.0;
-        for (int n = l; n < WLEN; n += 8) sacc += (double)span[base + n] * 32768.0;
+        for (int n = l; n < WLEN; n += 8) sacc += (double)fw[n] * 32768.0;
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
         if (l == 0) fmean[f] = sacc / (double)WLEN;
       }
     }
     __syncthreads();
-    // windowed sample: remove the DC offset, pre-emphasise against the un-emphasised neighbour (sample 0 against itself), povey
-    dft_power_mfma<FB_NFFT, FB_BINS, 3>(tw, power, [&](int f, int n) -> double {
-      const int nc = min(n, WLEN - 1);       // (the 512-point transform's samples 400 .. 511 are zero padding)
-      const int base = min(f, last) * HOP;
+    // windowed frames, once per group for all three waves: remove the DC offset, pre-emphasise against the un-emphasised
+    // neighbour (sample 0 against itself), povey window
+    for (int i = threadIdx.x; i < MF * WLEN; i += blockDim.x) {
+      const int f = i / WLEN, n = i - f * WLEN;
+      const float* fw = w + (int64_t)min(f0 + f, n_frames - 1) * HOP;
       const double mu = fmean[f];
-      const double cur = (double)span[base + nc] * 32768.0 - mu;
-      const double prev = (double)span[base + max(nc - 1, 0)] * 32768.0 - mu;
-      const double v = (cur - 0.97 * prev) * povey[nc];
+      const double cur = (double)fw[n] * 32768.0 - mu;
+      const double prev = (double)fw[max(n - 1, 0)] * 32768.0 - mu;
+      xwin[f * XP + n] = (cur - 0.97 * prev) * povey[n];
+    }
+    __syncthreads();
+    // (the 512-point transform's samples 400 .. 511 are zero padding)
+    dft_power_mfma<FB_NFFT, FB_BINS, 3, true>(tw, power, [&](int f, int n) -> double {
+      const double v = xwin[f * XP + min(n, WLEN - 1)];
       return n < WLEN ? v : 0.0;
     });
     __syncthreads();
