@@ -290,6 +290,33 @@ def test_attn_fwd_reads_kv_from_cache_layout(B, D, H, causal):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("D,H,causal,bias", [(64, 20, False, False), (64, 12, False, True), (128, 8, True, False), (64, 4, True, False)])
+def test_attn_fwd_is_bit_reproducible(B, D, H, causal, bias):
+    """The same call five times gives the same bits.  (A row maximum read from an MFMA result before the matrix pipe had
+    written it — an instruction-hazard bug of an intermediate round-2 build — showed up only as last-bit differences between
+    runs.)  Long enough for many interior tiles, ragged so the masked tail runs too."""
+    lens = [1500, 700, 129]
+    total = sum(lens)
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    q, k, v = (_rand_bf16(total, H * D, seed=301 + i) for i in range(3))
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    kw = {}
+    if bias:
+        span = max(lens)
+        kw = dict(rel_bias=torch.randn(H, 2 * span - 1, device=DEV), rel_gate=torch.rand(total, H, device=DEV) * 2, rel_span=span)
+    outs = []
+    for _ in range(5):
+        out = torch.empty(total, H * D, dtype=torch.bfloat16, device=DEV)
+        B.attn_fwd(q, k, v, out, cu_t, max(lens), H, D, D ** -0.5, causal=causal, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_attn_fwd_kv_lens_and_spike(B):
     # key padding + a spiked key that forces the online-softmax rescale late in the sequence
     D, H, lens = 64, 2, [300, 130]
@@ -516,6 +543,19 @@ def test_lora_down(B):
     a = _rand_bf16(r, K0, seed=44, scale=0.05)
     ref = (x[:, :K0].float() @ a.float().t() * 2.0)
     B.lora_down(x, K0, a, r, 2.0)
+    assert _relerr(x[:, K0:K0 + r], ref) < 4e-3
+    assert (x[:, K0 + r:] == 0).all()
+
+
+@pytest.mark.parametrize("r,K0", [(8, 4096), (16, 1280), (21, 512), (64, 4096), (3, 64)])
+def test_lora_down_ranks_and_depths(B, r, K0):
+    """rank counts that do not fill the four-row sweeps (3, 21), the maximum (64) and K not a multiple of the 512-wide step"""
+    M = 5
+    x = _rand_bf16(M, K0 + 64, seed=143)
+    x[:, K0:] = 0
+    a = _rand_bf16(r, K0, seed=144, scale=0.05)
+    ref = (x[:, :K0].float() @ a.float().t() * 0.5)
+    B.lora_down(x, K0, a, r, 0.5)
     assert _relerr(x[:, K0:K0 + r], ref) < 4e-3
     assert (x[:, K0 + r:] == 0).all()
 
