@@ -428,8 +428,9 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
   };
   // interior tiles first (whole tile inside kv_len and, when causal, at or below the wave's first query), then the rest;
   // the split is per wave, every wave still passes one barrier per tile
+  // (with the gated bias too: its interior body is the general path minus the mask and the key-index arithmetic)
   int t = 0;
-  if constexpr (!BIAS) {
+  {
     const int n_plain = min(n_tiles, CAUSAL ? min(kvlen, qw[0] + 1) >> 6 : kvlen >> 6);
     for (; t < n_plain; ++t) tile(t, std::false_type{});
   }
