@@ -398,7 +398,7 @@ def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
         if b_i + 1 >= max(2, n_batches // 2):
             break
     host_rate = n_host / (time.perf_counter() - t0)
-    tracker, done, t_start, prompt_tokens = None, 0, None, []
+    tracker, done, t_start, prompt_tokens, stages = None, 0, None, [], []
     with torch.no_grad():
         from icl_speech_text_llm_amd.utils.data_utils import device_prefetch
         for b_i, batch in enumerate(device_prefetch(loader(), dev)):      # as the CLI does: batch i+1's H2D under batch i's kernels
@@ -411,6 +411,8 @@ def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
             if tracker is not None:
                 tracker.update(time.perf_counter() - t1, len(batch["input_ids"]))
                 done += len(out)
+                st = dict(getattr(model, "last_stage_seconds", {}), total=time.perf_counter() - t1)
+                stages.append({k: round(v * 1e3, 1) for k, v in st.items()})
             if b_i == 0:
                 prompt_tokens = [len(model.llama_tokenizer(p, add_special_tokens=False)["input_ids"]) for p in batch["prompt"][:4]]
     torch.cuda.synchronize()
@@ -421,10 +423,15 @@ def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
     return {"utt_per_s": round(done / dt, 2), "examples_per_second_tracker": summ.get("examples_per_second"),
             "batch_size": bs, "batches_timed": n_batches, "dataloader_workers": args.plugin_workers,
             "host_ceiling_utt_per_s_per_rank": round(host_rate, 1),
+            "host_stage_ms_last_batch": stages[-1] if stages else None,
+            "generate_output_ms_per_batch": [st["total"] for st in stages],
+            "utt_per_s_steady": (round(bs / (sorted(st["total"] for st in stages)[len(stages) // 2] * 1e-3), 2) if stages else None),
             "prompt_positions_first_rows": [t + N_AUDIO_TOK for t in prompt_tokens],
             "note": "ModelFactory -> SalmonProcessor/DataLoader -> generate_output; H2D of raw audio, prompt split + tokenisation "
                     "(stand-in sub-word tokenizer at ~3.9 chars per token: no Llama tokenizer files offline; prompt positions as listed, vs the "
-                    "frozen 376), K1..K11 and batch_decode inside the timed region; first batches excluded as warm-up"}
+                    "frozen 376), K1..K11 and batch_decode inside the timed region; first batches excluded as warm-up; utt_per_s counts every "
+                    "timed batch (a batch whose ragged prompt lengths open a new decode-graph key pays its capture), utt_per_s_steady is "
+                    "the median batch"}
 
 
 def main():

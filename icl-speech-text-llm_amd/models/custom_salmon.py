@@ -474,9 +474,13 @@ class CustomSALMONN(BaseModel):
 
     # ---- forward / generate -----------------------------------------------------------------------------
     def forward(self, samples: Dict[str, Any]) -> Dict[str, Any]:
+        t0 = time.perf_counter()
+        samples = self._host_counts(samples)
         speech_embeds, _, example_embeds, _ = self.get_speech_embeddings(samples)
+        t1 = time.perf_counter()
         num_examples = samples.get("num_examples", torch.zeros(len(samples["prompt"]), dtype=torch.long))
         segs, speech = self._segments(speech_embeds, samples["prompt"], num_examples, example_embeds)
+        t2 = time.perf_counter()
         tgt = self.llama_tokenizer(samples["completion"], padding="longest", return_tensors="pt",
                                    add_special_tokens=False, return_attention_mask=True)
         tgt_ids, tgt_mask = tgt["input_ids"], tgt["attention_mask"]
@@ -495,15 +499,29 @@ class CustomSALMONN(BaseModel):
         self.batch_counter += 1
         return {"loss": loss, "logits": logits.view(B, S, -1).clone(), "labels": labels.to(logits.device)}
 
+    @staticmethod
+    def _host_counts(samples: Dict[str, Any]) -> Dict[str, Any]:
+        """``num_examples`` on the host BEFORE any kernel of the batch is launched: the prompt logic reads it element by element
+        (`_segments`, `get_speech_embeddings`), and reading a device tensor there waits for the speech encoders — the
+        tokenisation would then run after them instead of under them."""
+        ne = samples.get("num_examples")
+        if isinstance(ne, torch.Tensor) and ne.is_cuda:
+            samples = dict(samples, num_examples=ne.cpu())
+        return samples
+
     def generate_ids(self, samples: Dict[str, Any], want_first_logits: bool = False):
         """The arithmetic half of ``generate_output``: batch dict -> ``GenerateResult`` (new token ids int64 [B, width] with HF's
         EOS / pad / width rules, and the first-step logits f32 [B, V] on request).  The data-parallel CLI gathers these as
         fixed-shape tensors and decodes on rank 0."""
         if samples.get("num_beams", 1) != 1:
             raise NotImplementedError("the MI355X path implements greedy search and sampling, not beam search (num_beams=1)")
+        t0 = time.perf_counter()
+        samples = self._host_counts(samples)
         speech_embeds, _, example_embeds, _ = self.get_speech_embeddings(samples)
+        t1 = time.perf_counter()
         num_examples = samples.get("num_examples", torch.zeros(len(samples["prompt"]), dtype=torch.long))
         segs, speech = self._segments(speech_embeds, samples["prompt"], num_examples, example_embeds)
+        t2 = time.perf_counter()
         # generation knobs and their defaults as the reference reads them (:708-715); min_length / length_penalty have no
         # effect on this path (min_length is a no-op with inputs_embeds, length_penalty only acts on beams)
         res = self.runtime.generate(segs, speech, max_new_tokens=int(samples.get("max_new_tokens", 10)),
@@ -513,6 +531,9 @@ class CustomSALMONN(BaseModel):
                                     top_k=int(samples.get("top_k", 50)),
                                     repetition_penalty=float(samples.get("repetition_penalty", 1.0)),
                                     generator=samples.get("generator"), want_first_logits=want_first_logits)
+        # host-side stage times of the last batch (launch of the speech encoders / prompt split + tokenisation / decoder incl.
+        # the wait for the ids): the encoders run asynchronously under the tokenisation
+        self.last_stage_seconds = {"speech_launch": t1 - t0, "segments": t2 - t1, "generate": time.perf_counter() - t2}
         self.batch_counter += 1
         return res
 

@@ -56,7 +56,11 @@ def device_prefetch(loader, device):
 
     def ship(batch):
         with torch.cuda.stream(side):
-            out = {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            # only the floating-point payload (waveforms, spectrograms) goes to the device: lengths, masks and example counts
+            # are read on the host by the model's prompt logic, and a device copy would turn each such read into a stream sync
+            # in the middle of a batch (the encoders are running by then)
+            out = {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) and v.is_floating_point() else v)
+                   for k, v in batch.items()}
         ev = torch.cuda.Event()
         ev.record(side)
         return out, ev, batch          # keep the pinned host batch alive until its copy has been waited for
@@ -74,6 +78,6 @@ def device_prefetch(loader, device):
             pending = None
         torch.cuda.current_stream(dev).wait_event(ev)
         for v in cur.values():
-            if isinstance(v, torch.Tensor):
+            if isinstance(v, torch.Tensor) and v.is_cuda:
                 v.record_stream(torch.cuda.current_stream(dev))
         yield cur

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import logging
 import os
+import re
 from typing import List, Sequence, Union
 
 import torch
@@ -107,25 +108,23 @@ class SubwordStandInTokenizer(ByteTokenizer):
         super().__init__(vocab_size)
         self.piece = piece
         self._ids, self._pieces = {}, {}
+        self._split = re.compile(r"(?s).[^ \n]{0,%d}" % (piece - 1)).findall
 
     def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
         out: List[int] = [self.bos_token_id] if add_special_tokens else []
-        i, n = 0, len(text)
-        while i < n:
-            j = i + 1
-            while j < n and j - i < self.piece and text[j] not in " \n":       # a piece never crosses a word boundary
-                j += 1
-            p = text[i:j]
-            t = self._ids.get(p)
+        ids = self._ids
+        # a piece = one character (of any kind) + up to piece-1 following characters that are neither space nor newline, so
+        # it never crosses a word boundary; one regex pass instead of a per-character loop (128 prompts of ~1500 characters
+        # per batch sit on the host path of the plugin benchmark)
+        for p in self._split(text):
+            t = ids.get(p)
             if t is None:
-                t = 259 + len(self._ids)
+                t = 259 + len(ids)
                 if t >= self._vocab - 1:                  # vocabulary exhausted: fall back to bytes for this piece
                     out.extend(b + 3 for b in p.encode("utf-8"))
-                    i = j
                     continue
-                self._ids[p], self._pieces[t] = t, p
+                ids[p], self._pieces[t] = t, p
             out.append(t)
-            i = j
         return out
 
     def decode(self, ids, skip_special_tokens: bool = False, **_) -> str:
