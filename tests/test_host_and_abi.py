@@ -330,9 +330,14 @@ def test_workspace_capacity_is_bounded_and_tracks_generation():
         t = ws.get("pf_qkv", (m, 96), torch.bfloat16)
         assert t.shape == (m, 96) and t.is_contiguous()
         ws.get("pf_h", (m, 32), torch.float32)
-    assert ws.nbytes() == max(sizes) * (96 * 2 + 32 * 4)
+    assert max(sizes) * (96 * 2 + 32 * 4) <= ws.nbytes() <= int(max(sizes) * (96 * 2 + 32 * 4) * 1.0625) + 8   # 1/16 regrowth headroom
     gen = ws.generation
     assert 0 < gen <= 2 * 12          # ~ln(200) record highs per name, not one per shape
+    # the bench's ragged batches: totals that creep up by a fraction of a percent reallocate once, not once per record
+    ws2 = Workspace("cpu")
+    for m in (47744, 47900, 47950, 48000, 48128, 48100):
+        ws2.get("pf_h", (m, 8), torch.float32)
+    assert ws2.generation == 1
     a = ws.get("pf_qkv", (17, 96), torch.bfloat16)
     b = ws.get("pf_qkv", (4000, 96), torch.bfloat16)
     assert a.data_ptr() == b.data_ptr() and ws.generation == gen          # within capacity: same storage, no bump
