@@ -43,13 +43,13 @@ class Workspace:
         key = (name, dtype)
         ent = self._bufs.get(key)
         if ent is None or ent[0].numel() < n:
-            cap = max(n, 1)
+            # 1/16 of headroom on every allocation: ragged batches break their own size record by a fraction of a percent at a
+            # time (128 prompts of 373-376 positions), and every reallocation drops the captured decode graphs — without it a
+            # fresh runtime spends its first batches on eager, regrow + eager, capture
+            cap = max(n, 1) + (max(n, 1) >> 4)
             if ent is not None:
                 ent[0] = None                   # release the old block before asking for the larger one
                 self.generation += 1
-                # a buffer that had to grow once gets 1/16 of headroom: ragged batches break their own size record by a
-                # fraction of a percent at a time, and every reallocation drops the captured decode graphs
-                cap += cap >> 4
             flat = (torch.zeros if zero else torch.empty)(cap, dtype=dtype, device=self.device)
             ent = self._bufs[key] = [flat, shape[1:]]
         elif zero and ent[1] != shape[1:]:

@@ -337,7 +337,7 @@ def test_workspace_capacity_is_bounded_and_tracks_generation():
     ws2 = Workspace("cpu")
     for m in (47744, 47900, 47950, 48000, 48128, 48100):
         ws2.get("pf_h", (m, 8), torch.float32)
-    assert ws2.generation == 1
+    assert ws2.generation == 0
     a = ws.get("pf_qkv", (17, 96), torch.bfloat16)
     b = ws.get("pf_qkv", (4000, 96), torch.bfloat16)
     assert a.data_ptr() == b.data_ptr() and ws.generation == gen          # within capacity: same storage, no bump
