@@ -85,7 +85,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="utterances per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="utterances per step per GPU (prefilled 128 at a time, decoded together)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (cpu_baseline + parity)")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md §3 in full: 16 utterances at 8 threads and at all cores (median), plus config 1 "
@@ -100,7 +100,7 @@ def parse():
                          "the timed region; SURVEY.md §8d)")
     ap.add_argument("--no-through-plugin", action="store_true", help="skip the plugin-path leg")
     ap.add_argument("--plugin-workers", type=int, default=8)
-    ap.add_argument("--plugin-batch", type=int, default=128, help="batch size of the plugin-path leg (same micro-batch as the runtime number)")
+    ap.add_argument("--plugin-batch", type=int, default=256, help="batch size of the plugin-path leg (same micro-batch as the runtime number)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c2s", "c4", "c5"],
                     help="BASELINE.md §4: c2 = headline (default); c2s = 5 speech exemplars; c4 = Qwen2-Audio HVB; "
                          "c5 = Llama2-13B VOXCELEB+HVB+VOXPOPULI round-robin")

@@ -1004,7 +1004,7 @@ template <int DEPTH, int MT>   // DEPTH: K-tiles of W in registers (and of A in 
 __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
   constexpr int NI = 2, BN = 4 * NI * 16, A_INSTR = MT / 4, A_STAGE = MT * 16 * 128, NSA = DEPTH + 1;
   constexpr int G = A_INSTR + NI;   // VMEM loads per K-tile per lane
-  static_assert(MT == 8 || MT == 4, "128- or 64-row blocks");
+  static_assert(MT == 16 || MT == 8 || MT == 4, "256-, 128- or 64-row blocks");
   static_assert(NSA * A_STAGE >= 4 * MT * NI * 1024, "the K-half exchange reuses the A ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1080,14 +1080,19 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(GemmParams p) {
     stage_a(t + DEPTH, slot == 0 ? NSA - 1 : slot - 1);   // into the ring slot of t-1
     const char* a_s = smem + slot * A_STAGE + a_off;
     slot = slot == NSA - 1 ? 0 : slot + 1;
-    bf16x8 af[MT];
+    constexpr int MH = MT > 8 ? 8 : MT;      // activation fragments held at a time (256-row blocks take two passes: registers)
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(a_s + i * 16 * 128);
+    for (int ih = 0; ih < MT / MH; ++ih) {
+      bf16x8 af[MH];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MH; ++i) af[i] = *(const bf16x8*)(a_s + (ih * MH + i) * 16 * 128);
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], af[i], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[ih * MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], af[i], acc[ih * MH + i][j], 0, 0, 0);
+      if (MT > MH) __builtin_amdgcn_sched_barrier(0);      // keep the second pass's fragment reads behind the first pass's MFMAs
+    }
     __builtin_amdgcn_sched_barrier(0);
     load_w(w, t + DEPTH);                    // this register set is free again
     __builtin_amdgcn_sched_barrier(0);
@@ -1310,10 +1315,11 @@ static int gemm_impl(const icl_gemm_args* a, void* stream_, const RopeFuse* rope
     else    rc = mb <= 1 ? launch_skinny<1, 1, 8>(p, stream, pk) : mb == 2 ? launch_skinny<2, 1, 4>(p, stream, pk) : launch_skinny<4, 1, 2>(p, stream, pk);
     return rc;
   } else if (tile == 5) {
-    ICL_CHECK_ARG(a->M <= 128 && a->batch == 1, "icl_gemm_bf16: the decode tile needs M <= 128 and batch == 1");
+    ICL_CHECK_ARG(a->M <= 256 && a->batch == 1, "icl_gemm_bf16: the decode tile needs M <= 256 and batch == 1");
     // 256-column blocks when that still gives every CU most of a block, 128-column blocks otherwise
     // depth 3 / 4 / 6 measured alike: the CU's vector-memory path is the limit, not latency.  64-row blocks stage half the A bytes
-    rc = a->M <= 64 ? launch_m128<3, 4>(p, stream) : launch_m128<3, 8>(p, stream);
+    // 256-row blocks (two micro-batches decoded together): a weight byte then serves twice the rows
+    rc = a->M <= 64 ? launch_m128<3, 4>(p, stream) : a->M <= 128 ? launch_m128<3, 8>(p, stream) : launch_m128<3, 16>(p, stream);
   } else {
     icl_set_error("icl_gemm_bf16: unsupported tile id %d", tile);
     return ICL_EINVAL;

@@ -336,7 +336,7 @@ class SpeechQFormerHIP:
 # K9 + K10 + K11 (+K12 host side): Llama
 # ================================================================================================
 class LlamaHIP:
-    decode_packed_weights = True     # micro-batch <= 128: decode GEMMs stream decode-packed copies of the layer weights
+    decode_packed_weights = True     # micro-batch <= 256: decode GEMMs stream decode-packed copies of the layer weights
 
     def __init__(self, w: PackedLlama, device):
         self.w = w
@@ -454,8 +454,9 @@ class LlamaHIP:
         # Weights are streamed once per step, from decode-packed copies of the layer weights (made once, on the first decode
         # step: a second 12.9 GB for Llama-2-7B — the prefill kernels keep the row-major originals; HBM is sized for both): a
         # wave-load is 1 KB contiguous instead of 16 rows x 64 B.  Per layer, rotating weights: Bn <= 8 the skinny kernel
-        # (in-block split-K) 90-108 -> 79-87 us (5.1 TB/s at Bn = 1); 9..128 the decode tile (64- or 128-row blocks, about one
-        # block per CU) 115-167 -> 97-132 us; above 128 the 64x64 LDS tile + split-K on the row-major weights.
+        # (in-block split-K) 90-108 -> 79-87 us (5.1 TB/s at Bn = 1); 9..256 the decode tile (64-, 128- or 256-row blocks, about one
+        # block per CU) 115-167 -> 97-132 us at 128 rows, 214 us at 256 (0.84 vs 1.06 us per row: a weight byte serves twice the rows);
+        # above 256 the 64x64 LDS tile + split-K on the row-major weights.
         def sk(N, K):
             tiles = ((N + 63) // 64) * ((Bn + 63) // 64)
             s = max(1, min(K // 512, (2 * self.n_cu + tiles - 1) // tiles))
@@ -463,7 +464,7 @@ class LlamaHIP:
 
         def sk5(N, K):
             return max(1, min(self.n_cu // ((N + 127) // 128), K // 512))
-        if Bn <= 128 and self.decode_packed_weights:
+        if Bn <= 256 and self.decode_packed_weights:
             self.ensure_decode_packed()
             if Bn <= 8:
                 split = dict(tile=6)
@@ -495,3 +496,11 @@ class KVCache:
         shape = (cfg.n_layers, n_seqs, cfg.n_heads, max_len, cfg.head_dim)
         self.k = ws.get("kv_k", shape, BF16)
         self.v = ws.get("kv_v", shape, BF16)
+
+    def rows(self, b0: int, b1: int) -> "KVCache":
+        """The cache of sequences b0 .. b1-1 only (views; sequence ids inside are relative to b0): a prefill over a chunk of
+        the batch appends into, and reads from, its own block of the one allocation."""
+        sub = object.__new__(KVCache)
+        sub.n_seqs, sub.max_len = b1 - b0, self.max_len
+        sub.k, sub.v = self.k[:, b0:b1], self.v[:, b0:b1]
+        return sub

@@ -100,6 +100,8 @@ class CausalLMRuntimeMixin:
         move bumps ``ws.generation``, which retires every captured graph)."""
         return KVCache(self.lm_cfg, n_seqs, max_len, self.ws)
 
+    prefill_chunk = 128          # sequences per prefill pass of generate() (see there)
+
     def _graph_lookup(self, gkey):
         """(captured graph | None, warm?) for this key, after retiring everything captured or warmed under an older
         workspace generation: a graph bakes raw pointers into workspace buffers and must not outlive a reallocation."""
@@ -140,7 +142,19 @@ class CausalLMRuntimeMixin:
         marks = getattr(self, "phase_marks", None)     # optional {name: torch.cuda.Event}: bench.py times prefill / decode with it
         if marks is not None:
             marks["prefill_start"].record()
-        self.llama.prefill(ws, h, lens, cache)
+        # Prefill in chunks of at most ``prefill_chunk`` sequences, decode ALL of them together: the decode GEMMs stream the
+        # weights once per step whatever the row count (256 rows cost 0.84 us each against 1.06 at 128), while the prefill
+        # GEMMs measured 1.3 % faster per utterance at 128 sequences than at 256.  A sequence's arithmetic does not depend on
+        # its neighbours in either phase, so the split changes no result.
+        if Bn <= self.prefill_chunk:
+            self.llama.prefill(ws, h, lens, cache)
+        else:
+            r0 = 0
+            for b0 in range(0, Bn, self.prefill_chunk):
+                b1 = min(Bn, b0 + self.prefill_chunk)
+                r1 = r0 + sum(lens[b0:b1])
+                self.llama.prefill(ws, h[r0:r1], lens[b0:b1], cache.rows(b0, b1))
+                r0 = r1
         cu_last = []
         acc = 0
         for s in lens:

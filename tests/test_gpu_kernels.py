@@ -683,9 +683,10 @@ def test_gemm_skinny_swiglu(B, M):
 
 @pytest.mark.parametrize("M,N,K,split", [(128, 512, 4160, 1), (128, 4096, 1024, 4), (65, 768, 64, 1), (100, 200, 576, 3),
                                          (97, 12288, 192, 1), (128, 8192, 2048, 5), (77, 264, 320, 5),
-                                         (64, 4096, 1024, 2), (9, 520, 576, 1), (33, 1000, 320, 3)])   # 64-row blocks
+                                         (64, 4096, 1024, 2), (9, 520, 576, 1), (33, 1000, 320, 3),     # 64-row blocks
+                                         (256, 512, 4160, 1), (200, 4096, 1024, 4), (129, 264, 320, 5), (256, 768, 64, 1)])   # 256-row blocks
 def test_gemm_m128_decode_kernel(B, M, N, K, split):
-    """Decode tile for 64 < M <= 128 (decode-packed weights HBM -> VGPR, activations through an LDS ring): ragged M and N,
+    """Decode tile for M <= 256 (decode-packed weights HBM -> VGPR, activations through an LDS ring): ragged M and N,
     K ranges shorter than the prefetch depth, split-K with uneven slices, f32 + bias + residual and bf16 outputs."""
     a, w = _rand_bf16(M, K, seed=61, scale=0.5), _rand_bf16(N, K, seed=62, scale=0.05)
     bias, res = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV)
@@ -705,7 +706,21 @@ def test_gemm_m128_decode_kernel(B, M, N, K, split):
     assert (out[:M] - out2).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("M,split", [(128, 1), (90, 2)])
+def test_gemm_m128_rows_do_not_depend_on_the_block_height(B):
+    """A row's sums are the same MFMAs in the same order whether it is computed in a 64-, 128- or 256-row block: decoding two
+    micro-batches together must not change a sequence's logits."""
+    N, K = 1024, 4160
+    a, w = _rand_bf16(256, K, seed=161, scale=0.5), _rand_bf16(N, K, seed=162, scale=0.05)
+    wp = B.pack_decode_weights(w)
+    outs = {}
+    for M in (40, 128, 256):
+        o = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        B.gemm(a[:M], wp, o, tile=5, M=M, N=N)
+        outs[M] = o
+    assert torch.equal(outs[256][:128], outs[128]) and torch.equal(outs[128][:40], outs[40])
+
+
+@pytest.mark.parametrize("M,split", [(128, 1), (90, 2), (256, 1), (130, 3)])
 def test_gemm_m128_swiglu(B, M, split):
     I, K = 11008 // 4, 512
     a = _rand_bf16(M, K, seed=63, scale=0.5)

@@ -334,6 +334,27 @@ def test_generate_sampled_and_penalised_greedy(env):
         assert ids.shape == (1, 3)
 
 
+def test_generate_with_chunked_prefill_is_bit_identical(env):
+    """generate() prefills at most ``prefill_chunk`` sequences at a time into their own block of the one KV cache and decodes all
+    of them together: first-step logits and every token equal the single-pass result, for chunk sizes that divide the batch and
+    that leave a ragged last chunk."""
+    cfg, sd, rt = env
+    lens = [37, 64, 5, 50, 21, 44, 9]
+    prompts = _prompts(cfg, lens, seed=4100)
+    keep = rt.prefill_chunk
+    try:
+        rt.prefill_chunk = 128
+        want = rt.generate(prompts, None, max_new_tokens=6, suppress_eos=True, want_first_logits=True)
+        want_tok, want_first = want.tokens.clone(), want.first_logits.clone()
+        for chunk in (1, 3, 4):
+            rt.prefill_chunk = chunk
+            got = rt.generate(prompts, None, max_new_tokens=6, suppress_eos=True, want_first_logits=True)
+            assert torch.equal(got.first_logits, want_first), f"chunk {chunk}: first-step logits differ"
+            assert torch.equal(got.tokens, want_tok), f"chunk {chunk}: tokens differ"
+    finally:
+        rt.prefill_chunk = keep
+
+
 def test_workspace_stays_bounded_over_ragged_batches(env):
     """a dataset run sees a new total row count on almost every batch.  60 ragged batches (distinct packed
     row totals, batch sizes 1..6, audio 1..4 s) after one largest-shape call must not grow the workspace by a byte, must not

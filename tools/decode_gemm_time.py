@@ -1,0 +1,32 @@
+"""Times the decode tile (icl_gemm_bf16 tile 5) at the four per-layer decode shapes of Llama-2-7B for 128 and 256 rows, with
+rotating weight copies so nothing is served from cache (per-layer microseconds and the weight stream rate)."""
+import os, sys
+import torch
+sys.path.insert(0, ".")
+from icl_speech_text_llm_amd.runtime import binding as B
+if os.environ.get("ICL_LIB"):
+    B.LIB_PATH = os.environ["ICL_LIB"]
+B.load_library()
+DEV, NCU, COPIES = "cuda", 256, 6
+def sk5(N, K): return max(1, min(NCU // ((N + 127) // 128), K // 512))
+shapes = [("qkv", 12288, 4160, False), ("o", 4096, 4096, False), ("gate/up", 22016, 4096, True), ("down", 4096, 11008, False)]
+for M in (128, 256):
+    tot = 0.0
+    for name, N, K, sw in shapes:
+        g = torch.Generator().manual_seed(1)
+        a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+        ws_ = [B.pack_decode_weights((torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)) for _ in range(COPIES)]
+        split = sk5(N, K)
+        wsk = torch.empty(split * M * N, device=DEV) if split > 1 else None
+        out = torch.empty(M, N // 2 if sw else N, dtype=torch.bfloat16, device=DEV)
+        def run(i): B.gemm(a, ws_[i % COPIES], out, swiglu=sw, tile=5, split_k=split, workspace=wsk, M=M, N=N)
+        for i in range(COPIES): run(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(10 * COPIES): run(i)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / (10 * COPIES) * 1e3
+        tot += us
+        print(f"M={M} {name:8s} N={N} K={K} split={split}: {us:7.1f} us  {N*K*2/us/1e6:5.2f} TB/s of weights")
+    print(f"M={M}: {tot:.1f} us per layer = {tot/M:.3f} us per row")
