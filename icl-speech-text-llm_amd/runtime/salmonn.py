@@ -9,6 +9,8 @@ gather kernel (K9).  Everything arithmetic goes through libicl_hip; there is no 
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -100,7 +102,7 @@ class CausalLMRuntimeMixin:
         move bumps ``ws.generation``, which retires every captured graph)."""
         return KVCache(self.lm_cfg, n_seqs, max_len, self.ws)
 
-    prefill_chunk = 128          # sequences per prefill pass of generate() (see there)
+    prefill_chunk = int(os.environ.get("ICL_PREFILL_CHUNK", "128"))   # sequences per prefill pass of generate() (see there)
 
     def _graph_lookup(self, gkey):
         """(captured graph | None, warm?) for this key, after retiring everything captured or warmed under an older
