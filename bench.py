@@ -385,7 +385,9 @@ def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
     model = ModelFactory.create_model("salmonn", device=str(dev), arch="tiny" if args.tiny else "7b", low_resource=True,
                                       llama_path="stand-in:subword", ckpt_path="", lora_alpha=32).eval()
     proc = get_processor("salmonn", model.input_processor, model.llama_tokenizer)
-    ds = SyntheticICLDataset(proc, [DatasetType.VOXCELEB], n_items=bs * (n_batches + warm), num_examples=5,
+    # one batch more than is consumed: the loop below stops before the loader is exhausted, so that tearing the DataLoader's
+    # workers down (~0.3 s, once per epoch) does not land between two timed batches of a five-batch measurement
+    ds = SyntheticICLDataset(proc, [DatasetType.VOXCELEB], n_items=bs * (n_batches + warm + 1), num_examples=5,
                              input_mode="speech_only", fewshot_mode="text", audio_seconds=30.0)
 
     def loader():
@@ -398,7 +400,7 @@ def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
         if b_i + 1 >= max(2, n_batches // 2):
             break
     host_rate = n_host / (time.perf_counter() - t0)
-    tracker, done, t_start, prompt_tokens, stages = None, 0, None, [], []
+    tracker, done, t_start, prompt_tokens, stages, gaps, t_prev_end = None, 0, None, [], [], [], None
     with torch.no_grad():
         from icl_speech_text_llm_amd.utils.data_utils import device_prefetch
         for b_i, batch in enumerate(device_prefetch(loader(), dev)):      # as the CLI does: batch i+1's H2D under batch i's kernels
@@ -407,7 +409,10 @@ def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
                 tracker, t_start = PerformanceTracker(log_interval=10 ** 9), time.perf_counter()
             batch["max_new_tokens"] = NEW_TOKENS
             t1 = time.perf_counter()
+            if t_prev_end is not None and tracker is not None:
+                gaps.append(round((t1 - t_prev_end) * 1e3, 1))
             out = model.generate_output(batch)
+            t_prev_end = time.perf_counter()
             if tracker is not None:
                 tracker.update(time.perf_counter() - t1, len(batch["input_ids"]))
                 done += len(out)
@@ -415,8 +420,11 @@ def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
                 stages.append({k: round(v * 1e3, 1) for k, v in st.items()})
             if b_i == 0:
                 prompt_tokens = [len(model.llama_tokenizer(p, add_special_tokens=False)["input_ids"]) for p in batch["prompt"][:4]]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t_start
+            if b_i + 1 >= warm + n_batches:
+                torch.cuda.synchronize()
+                t_end = time.perf_counter()        # before the break: leaving the loop finalises the prefetcher and with it the
+                break                              # DataLoader's workers
+    dt = t_end - t_start
     summ = tracker.get_summary()
     del model
     torch.cuda.empty_cache()
@@ -425,6 +433,7 @@ def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
             "host_ceiling_utt_per_s_per_rank": round(host_rate, 1),
             "host_stage_ms_last_batch": stages[-1] if stages else None,
             "generate_output_ms_per_batch": [st["total"] for st in stages],
+            "between_batches_ms": gaps,
             "utt_per_s_steady": (round(bs / (sorted(st["total"] for st in stages)[len(stages) // 2] * 1e-3), 2) if stages else None),
             "prompt_positions_first_rows": [t + N_AUDIO_TOK for t in prompt_tokens],
             "note": "ModelFactory -> SalmonProcessor/DataLoader -> generate_output; H2D of raw audio, prompt split + tokenisation "
