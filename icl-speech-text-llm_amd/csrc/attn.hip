@@ -510,11 +510,16 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
 // both blocks, exactly as above; the scalar (non-packed) score math keeps the shadow usable.  Arithmetic per query is that of
 // the generic kernel operation for operation (k-step order per accumulator, softmax formulas, sequential row sum).
 // (the causal form is not on any model's path here: it gets the registers it asks for instead of spilling at two waves per SIMD)
-template <bool CAUSAL>
-__global__ __launch_bounds__(256, CAUSAL ? 1 : 2) void attn_fwd_il64_kernel(AttnParams p) {
-  constexpr int D = 64, QB = 2, BQ = 128 * QB, ROWB = D * 2, KS = D / 16, DB = D / 32, CPR = D / 8;
-  constexpr int NCH = 64 * CPR / 256, RPI = 64 / CPR, BUF = 2 * 64 * ROWB, NBUF = 3;
-  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF];
+#ifndef IL64_NW
+#define IL64_NW 4      // waves per workgroup of the interleaved kernel (64 queries each).  8 (512 queries share a staged K / V tile,
+                       // half the LDS-DMA instructions per wave) is bit-identical and measured 2-3.5 % SLOWER on both encoder shapes
+#endif
+template <bool CAUSAL, int NW>
+__global__ __launch_bounds__(64 * NW, CAUSAL ? 1 : 2) void attn_fwd_il64_kernel(AttnParams p) {
+  constexpr int D = 64, QB = 2, BQ = 32 * NW * QB, ROWB = D * 2, KS = D / 16, DB = D / 32, CPR = D / 8;
+  constexpr int NCH = 64 * CPR / (64 * NW), RPI = 64 / CPR, BUF = 2 * 64 * ROWB, NBUF = 3;
+  constexpr int EPI = NW * QB * 32 * (D * 2 + 16);       // the epilogue's per-wave transposition buffers reuse the ring
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF > EPI ? NBUF * BUF : EPI];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hh = lane >> 5;
@@ -667,7 +672,8 @@ __global__ __launch_bounds__(256, CAUSAL ? 1 : 2) void attn_fwd_il64_kernel(Attn
 
   stage_tile(0, 0);
   stage_tile(min(1, n_tiles - 1), 1);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (NCH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   __syncthreads();
   int cur = 0;
 
@@ -753,7 +759,8 @@ __global__ __launch_bounds__(256, CAUSAL ? 1 : 2) void attn_fwd_il64_kernel(Attn
 #pragma unroll
         for (int d = 0; d < DB; ++d)
           o_acc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb][s][d], pf1[kb][s], o_acc[1][d], 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's share of tile t+1 has landed; t+2 stays in flight
+    if constexpr (NCH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's share of tile t+1 has landed; t+2 stays in flight
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     cur = cur + 1 == NBUF ? 0 : cur + 1;
   };
@@ -817,12 +824,12 @@ __global__ __launch_bounds__(256, CAUSAL ? 1 : 2) void attn_fwd_il64_kernel(Attn
 
 template <int D>
 int launch_attn(const AttnParams& p, const icl_attn_args* a, hipStream_t stream) {
-  const int bq = (D == 64 && !a->rel_bias) ? 256 : 128;   // queries per workgroup
+  const int bq = (D == 64 && !a->rel_bias) ? IL64_NW * 64 : 128;   // queries per workgroup
   dim3 grid(((a->max_seqlen + bq - 1) / bq) * a->n_heads * a->n_seqs, 1, 1);
   const bool bias = a->rel_bias != nullptr;
   if (D == 64 && !bias) {
-    if (a->causal) hipLaunchKernelGGL((attn_fwd_il64_kernel<true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((attn_fwd_il64_kernel<false>), grid, dim3(256), 0, stream, p);
+    if (a->causal) hipLaunchKernelGGL((attn_fwd_il64_kernel<true, IL64_NW>), grid, dim3(64 * IL64_NW), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_il64_kernel<false, IL64_NW>), grid, dim3(64 * IL64_NW), 0, stream, p);
     ICL_CHECK_LAUNCH("icl_attn_fwd_bf16");
     return ICL_OK;
   }
@@ -872,7 +879,7 @@ extern "C" int icl_attn_fwd_bf16(const icl_attn_args* a, void* stream) {
   p.kv_seq_stride = a->kv_seq_stride; p.kv_head_stride = a->kv_head_stride;
   p.n_heads = a->n_heads;
   p.rel_span = a->rel_span;
-  const int bq = (a->head_dim == 64 && !a->rel_bias) ? 256 : 128;
+  const int bq = (a->head_dim == 64 && !a->rel_bias) ? IL64_NW * 64 : 128;
   p.n_qblocks = (a->max_seqlen + bq - 1) / bq;
   p.scale_log2e = a->scale * LOG2E;
   return a->head_dim == 64 ? launch_attn<64>(p, a, (hipStream_t)stream) : launch_attn<128>(p, a, (hipStream_t)stream);
