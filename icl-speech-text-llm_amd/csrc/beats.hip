@@ -6,12 +6,24 @@
 
 namespace {
 
+// The audio a packed row belongs to: the largest a with cu[a] + pad * a <= row, by bisection (every block of these kernels
+// starts with it; walking the prefix sums one dependent global load at a time cost ~50 us per block at 256 clips —
+// 6.6 ms of the 7 the pos-conv pack took).
+__device__ __forceinline__ int audio_of(const int* cu, int n_audio, int row, int pad) {
+  int lo = 0, hi = n_audio - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cu[mid] + pad * mid <= row) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
 // fbank f32 [n_audio][max_frames][128] -> patches bf16 [cu[a] + t'*8 + f'][i*16 + j] = fbank[a][16t'+i][16f'+j]
 __global__ __launch_bounds__(256) void beats_patchify_kernel(const float* fbank, int max_frames, const int* cu,
                                                               int n_audio, unsigned short* out) {
   const int row = blockIdx.x;  // packed patch row
-  int a = 0;
-  while (a + 1 < n_audio && row >= cu[a + 1]) ++a;
+  const int a = audio_of(cu, n_audio, row, 0);
   const int local = row - cu[a];
   const int tp = local >> 3, fp = local & 7;
   const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
@@ -24,14 +36,9 @@ __global__ __launch_bounds__(256) void beats_patchify_kernel(const float* fbank,
 __global__ __launch_bounds__(256) void beats_posconv_pack_kernel(float* x, const int* cu, const int* valid,
                                                                   int n_audio, int C, int G, unsigned short* xg) {
   // one block per padded row index of one audio: blockIdx.x enumerates (audio, r) over sum(T_a + 128)
-  int a = 0, r = blockIdx.x;
-  while (a < n_audio) {
-    const int span = cu[a + 1] - cu[a] + 128;
-    if (r < span) break;
-    r -= span;
-    ++a;
-  }
-  if (a >= n_audio) return;
+  if ((int)blockIdx.x >= cu[n_audio] + 128 * n_audio) return;
+  const int a = audio_of(cu, n_audio, blockIdx.x, 128);
+  const int r = blockIdx.x - (cu[a] + 128 * a);
   const int T = cu[a + 1] - cu[a];
   const int t = r - 64;
   const bool live = (t >= 0) && (t < T) && (t < valid[a]);

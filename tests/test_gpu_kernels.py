@@ -560,6 +560,45 @@ def test_lora_down_ranks_and_depths(B, r, K0):
     assert (x[:, K0 + r:] == 0).all()
 
 
+def test_beats_patchify_and_posconv_pack_ragged(B):
+    """The two BEATs data movers against plain indexing, many ragged audios (every block finds its audio by bisection over
+    the packed-row prefix sums): 16x16 patches of the fbank, and the zero-padded per-group image of the positional conv with
+    padded rows zeroed in place."""
+    rng = np.random.default_rng(7)
+    n_audio, max_frames = 37, 160
+    frames = rng.integers(1, max_frames // 16 + 1, n_audio) * 16            # whole 16-frame patches
+    fb = torch.randn(n_audio, max_frames, 128, device=DEV)
+    rows = [int(f // 16) * 8 for f in frames]
+    cu = np.concatenate([[0], np.cumsum(rows)]).astype(np.int32)
+    total = int(cu[-1])
+    out = torch.zeros(total, 256, dtype=torch.bfloat16, device=DEV)
+    B.beats_patchify(fb, torch.from_numpy(cu).to(DEV), total, out)
+    for a in (0, 1, 17, n_audio - 1):
+        T = int(frames[a]) // 16
+        ref = fb[a, :T * 16].view(T, 16, 8, 16).permute(0, 2, 1, 3).reshape(T * 8, 256).to(torch.bfloat16)
+        assert torch.equal(out[cu[a]:cu[a + 1]], ref), f"patchify: audio {a}"
+    # positional-conv image: x [M, C] -> per audio [G][T + 128][C / G] with 64 zero rows in front and behind, padded rows zeroed
+    C, G = 768, 16
+    T_rows = rng.integers(1, 40, n_audio)
+    cu2 = np.concatenate([[0], np.cumsum(T_rows)]).astype(np.int32)
+    valid = np.minimum(T_rows, rng.integers(1, 40, n_audio)).astype(np.int32)
+    M = int(cu2[-1])
+    x = torch.randn(M, C, device=DEV)
+    x0 = x.clone()
+    xg = torch.full((M + 128 * n_audio, C), float("nan"), dtype=torch.bfloat16, device=DEV).view(-1)
+    B.beats_posconv_pack(x, torch.from_numpy(cu2).to(DEV), torch.from_numpy(valid).to(DEV), n_audio, M, G, xg)
+    cpg = C // G
+    for a in range(n_audio):
+        T, v = int(T_rows[a]), int(valid[a])
+        xa = x0[cu2[a]:cu2[a + 1]].clone()
+        xa[v:] = 0
+        assert torch.equal(x[cu2[a]:cu2[a + 1]], xa), f"posconv: audio {a} rows past valid must be zeroed in place"
+        img = xg[(int(cu2[a]) + 128 * a) * C:(int(cu2[a + 1]) + 128 * (a + 1)) * C].view(G, T + 128, cpg)
+        ref = torch.zeros(G, T + 128, cpg, dtype=torch.bfloat16, device=DEV)
+        ref[:, 64:64 + T] = xa.view(T, G, cpg).permute(1, 0, 2).to(torch.bfloat16)
+        assert torch.equal(img, ref), f"posconv: audio {a} image"
+
+
 def test_beats_gate(B):
     M, H = 50, 12
     qkv = _rand_bf16(M, 3 * H * 64, seed=45)
