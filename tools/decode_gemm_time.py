@@ -10,6 +10,26 @@ B.load_library()
 DEV, NCU, COPIES = "cuda", 256, 6
 def sk5(N, K): return max(1, min(NCU // ((N + 127) // 128), K // 512))
 shapes = [("qkv", 12288, 4160, False), ("o", 4096, 4096, False), ("gate/up", 22016, 4096, True), ("down", 4096, 11008, False)]
+SWEEP = os.environ.get("ICL_SPLIT_SWEEP")          # e.g. "o:2,4,8,16;down:2,4,8,16;qkv:1,2,4" -> time each split at M = 256
+if SWEEP:
+    want = {kv.split(":")[0]: [int(x) for x in kv.split(":")[1].split(",")] for kv in SWEEP.split(";")}
+    M = 256
+    for name, N, K, sw in shapes:
+        for split in want.get(name, []):
+            g = torch.Generator().manual_seed(1)
+            a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+            ws_ = [B.pack_decode_weights((torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)) for _ in range(COPIES)]
+            wsk = torch.empty(split * M * N, device=DEV) if split > 1 else None
+            out = torch.empty(M, N // 2 if sw else N, dtype=torch.bfloat16, device=DEV)
+            def run(i): B.gemm(a, ws_[i % COPIES], out, swiglu=sw, tile=5, split_k=split, workspace=wsk, M=M, N=N)
+            for i in range(COPIES): run(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(10 * COPIES): run(i)
+            e1.record(); torch.cuda.synchronize()
+            print(f"M={M} {name:8s} split={split:2d}: {e0.elapsed_time(e1) / (10 * COPIES) * 1e3:7.1f} us")
+    sys.exit(0)
 for M in (128, 256):
     tot = 0.0
     for name, N, K, sw in shapes:
