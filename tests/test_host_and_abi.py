@@ -431,3 +431,25 @@ def test_audio_cells_decode_without_a_datasets_backend(tmp_path):
     finally:
         tc.set_dataset_root(None)
         clear_dataset_cache()
+
+
+def test_inline_asm_in_csrc_is_limited_to_memory_and_wait_instructions():
+    """hipcc's hazard recogniser does not look inside asm statements: a vector instruction written as inline asm can be scheduled
+    right behind the MFMA that produces its operand and read it before the matrix pipe has written it (round 2 found a row
+    maximum going stale that way).  Inline asm in the kernels is therefore limited to waits, LDS / global reads and
+    empty scheduling pins; arithmetic goes through the compiler."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "icl-speech-text-llm_amd", "csrc")
+    allow = {"s_waitcnt", "ds_read_b128", "ds_read_b64_tr_b16", "global_load_dwordx4"}
+    seen, bad = 0, []
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        for m in re.finditer(r'\basm\s*(?:volatile\s*)?\(\s*"([^"]*)"', open(f).read()):
+            for ins in re.split(r"\\n\\t|\\n|;", m.group(1)):
+                ins = ins.strip()
+                if ins:
+                    seen += 1
+                    if ins.split()[0] not in allow:
+                        bad.append((os.path.basename(f), ins[:60]))
+    assert seen > 10 and not bad, bad
