@@ -673,6 +673,13 @@ def main():
             "workspace_gib": round(rt.ws.nbytes() / 2 ** 30, 2),
             "build_s": round(t_build, 1), "first_utterance_tokens": first_tokens,
         }
+        out["hbm_peak_gib_timed_loop"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)
+        if world == 1:
+            # the side legs below build a second model (plugin) and a third set of decoder weights (margin parity) next to this
+            # one: hand the 94 GiB of micro-batch-256 workspace back first (the parity legs run one utterance and re-grow
+            # what they need)
+            rt.ws.clear()
+            torch.cuda.empty_cache()
         if world == 1 and args.workload == "c2" and not args.no_through_plugin and (args.through_plugin or not args.tiny):
             log("through-plugin leg ...")
             try:

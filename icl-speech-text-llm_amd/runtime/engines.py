@@ -60,6 +60,11 @@ class Workspace:
     def nbytes(self) -> int:
         return sum(e[0].numel() * e[0].element_size() for e in self._bufs.values())
 
+    def clear(self) -> None:
+        """Drop every buffer (they are re-created on demand).  Counts as a move: captured graphs are retired."""
+        self._bufs.clear()
+        self.generation += 1
+
 
 def _i32(x, device) -> torch.Tensor:
     return torch.as_tensor(x, dtype=I32).to(device, non_blocking=True)
