@@ -93,6 +93,7 @@ def parse():
     ap.add_argument("--cpu-baseline-out", default=None)
     ap.add_argument("--no-gemm-profile", action="store_true", help="no per-launch HIP events in the timed region (roofline = null)")
     ap.add_argument("--no-graphs", action="store_true", help="run the decode loop eagerly (rocprofv3 --pmc crashes on HIP-graph capture)")
+    ap.add_argument("--no-phases", action="store_true", help="skip the extra untimed per-phase step (profiling passes: fewer dispatches)")
     ap.add_argument("--tiny", action="store_true", help="miniature model (smoke only; not a valid bench number)")
     ap.add_argument("--through-plugin", action="store_true",
                     help="(default at N=1 on the headline workload) also time the path through the reference-compatible plugin: "
@@ -630,7 +631,7 @@ def main():
                 f"{fl / tt / 1e12:7.1f} TF/s, {100 * tt / elapsed:5.1f}% of step time")
     # ---- per-phase timing: ONE extra, untimed step with HIP events at the phase boundaries -----------------
     phases = None
-    if rank == 0 and args.workload == "c2" and not args.tiny:
+    if rank == 0 and args.workload == "c2" and not args.tiny and not args.no_phases:
         marks = {k: torch.cuda.Event(enable_timing=True) for k in ("enc_start", "prefill_start", "prefill_end", "decode_end")}
         rt.phase_marks = marks
         marks["enc_start"].record()

@@ -13,157 +13,12 @@
 //     blocks resident on one XCD form an 8x8 super-tile sharing A and W panels in that L2.
 // Tiles: 128x128 (2x2 waves, 4x4 MFMA tiles per wave) for prefill/encoder shapes,
 //        64x64   (2x2 waves, 2x2 MFMA tiles per wave) for skinny / decode shapes (+ split-K).
-#include "common.h"
-#include <algorithm>
-#include <type_traits>
+#include "gemm_common.h"
+
+using namespace iclg;
 
 namespace {
 
-struct GemmParams {
-  const __bf16* A;
-  const __bf16* W;
-  void* C;
-  const float* bias;
-  const void* R;
-  float* ws;
-  int64_t lda, ldw, ldc, ldr, sA, sC, sR;
-  int M, N, K, epi, out_dtype, res_dtype, split_k, tiles_m, tiles_n;
-};
-
-constexpr int GROUP_M = 8;
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-
-// ---- epilogue helpers shared by all tile shapes ---------------------------------------------------------
-// v[0..3] = C[m][n..n+3] (4 consecutive n owned by one lane).
-__device__ __forceinline__ void epi_store4(const GemmParams& p, int z, int m, int n, f32x4 acc) {
-  if (m >= p.M || n >= p.N) return;
-  const bool has_bias = p.epi & ICL_EPI_BIAS, has_gelu = p.epi & ICL_EPI_GELU, has_res = p.epi & ICL_EPI_RESIDUAL;
-  char* Cb = (char*)p.C;
-  const int64_t cz = (int64_t)z * p.sC, rz = (int64_t)z * p.sR;
-  const bool vec_ok = ((p.ldc & 3) == 0) && (!has_res || (p.ldr & 3) == 0);
-  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  const bool full = (n + 3 < p.N);
-  if (has_bias) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (full || n + r < p.N) v[r] += p.bias[n + r];
-  }
-  if (has_gelu) {
-    const f32x4 g = gelu_erf4(f32x4{v[0], v[1], v[2], v[3]});
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = g[r];
-  }
-  const int64_t coff = cz + (int64_t)m * p.ldc + n;
-  if (full && vec_ok) {
-    if (has_res) {
-      const int64_t roff = rz + (int64_t)m * p.ldr + n;
-      if (p.res_dtype == ICL_F32) {
-        f32x4 rv = *(const f32x4*)((const char*)p.R + roff * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rv[r];
-      } else {
-        const unsigned short* rp = (const unsigned short*)p.R + roff;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += bf16_bits_to_f32(rp[r]);
-      }
-    }
-    if (p.out_dtype == ICL_BF16) {
-      u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      *(u32x2*)(Cb + coff * 2) = pk;
-    } else {
-      *(f32x4*)(Cb + coff * 4) = f32x4{v[0], v[1], v[2], v[3]};
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (n + r >= p.N) continue;
-      float x = v[r];
-      if (has_res) {
-        const int64_t roff = rz + (int64_t)m * p.ldr + n + r;
-        x += (p.res_dtype == ICL_F32) ? ((const float*)p.R)[roff]
-                                      : bf16_bits_to_f32(((const unsigned short*)p.R)[roff]);
-      }
-      if (p.out_dtype == ICL_BF16)
-        ((unsigned short*)Cb)[coff + r] = f32_to_bf16_bits(x);
-      else
-        ((float*)Cb)[coff + r] = x;
-    }
-  }
-}
-// gate block at interleaved rows nt + fq4 + r, up block 16 rows later; output column nt/2 + fq4 + r
-__device__ __forceinline__ void epi_store_swiglu(const GemmParams& p, int z, int m, int nt, int fq4, f32x4 g4, f32x4 u4) {
-  if (m >= p.M || nt >= p.N) return;
-  float v[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float g = g4[r], u = u4[r];
-    if (p.epi & ICL_EPI_BIAS) {
-      g += p.bias[nt + fq4 + r];
-      u += p.bias[nt + 16 + fq4 + r];
-    }
-    v[r] = silu_f(g) * u;
-  }
-  const int64_t off = (int64_t)z * p.sC + (int64_t)m * p.ldc + (nt >> 1) + fq4;
-  if (p.out_dtype == ICL_BF16) {
-    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    *(u32x2*)((char*)p.C + off * 2) = pk;
-  } else {
-    *(f32x4*)((char*)p.C + off * 4) = f32x4{v[0], v[1], v[2], v[3]};
-  }
-}
-__device__ __forceinline__ void epi_store_partial(const GemmParams& p, int z, int m, int n, f32x4 acc) {
-  if (m >= p.M || n >= p.N) return;
-  float* dst = p.ws + (int64_t)z * p.M * p.N + (int64_t)m * p.N + n;
-  if (n + 3 < p.N && (p.N & 3) == 0) {
-    *(f32x4*)dst = acc;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (n + r < p.N) dst[r] = acc[r];
-  }
-}
-
-// ---- interior-tile fast path: no bounds checks, bias as one 16-B load per n-fragment (prefetched before the K loop),
-// ---- residual fragments loaded as ONE batch (independent loads in flight together), then add + convert + store.
-__device__ __forceinline__ f32x4 load_res4(const GemmParams& p, int64_t roff) {
-  if (p.res_dtype == ICL_F32) return *(const f32x4*)((const char*)p.R + roff * 4);
-  const u32x2 raw = *(const u32x2*)((const char*)p.R + roff * 2);
-  return f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
-               __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
-}
-__device__ __forceinline__ void store_out4(const GemmParams& p, int64_t coff, f32x4 v) {
-  if (p.out_dtype == ICL_BF16) {
-    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    *(u32x2*)((char*)p.C + coff * 2) = pk;
-  } else {
-    *(f32x4*)((char*)p.C + coff * 4) = v;
-  }
-}
-// Tile-INDEPENDENT vector-path predicate: whether a row's arithmetic order (accumulator init = bias + residual) may
-// depend only on the problem, never on which tile of the grid the row falls in -> results are batch-invariant.
-__device__ __forceinline__ bool vec_path_ok(const GemmParams& p) {
-  const bool has_res = p.epi & ICL_EPI_RESIDUAL;
-  return ((p.ldc & 3) == 0) && ((p.N & 3) == 0) && (!has_res || (p.ldr & 3) == 0) &&
-         (!(p.epi & ICL_EPI_BIAS) || (((uintptr_t)p.bias & 15) == 0));
-}
-__device__ __forceinline__ bool tile_is_interior(const GemmParams& p, int m0, int n0, int BM, int BN) {
-  return (m0 + BM <= p.M) && (n0 + BN <= p.N) && vec_path_ok(p);
-}
-__device__ __forceinline__ void block_to_tile(const GemmParams& p, int bid, int& tm, int& tn) {
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);   // bijective XCD remap
-  const int per_group = GROUP_M * p.tiles_n;
-  const int group = wgid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = min(p.tiles_m - first_m, GROUP_M);
-  const int in_group = wgid - group * per_group;
-  tm = first_m + in_group % gsize;
-  tn = in_group / gsize;
-}
 
 template <int WAVES_M, int WAVES_N, int MI, int NI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
@@ -408,478 +263,6 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-
-// =================================================================================================================
-// 256x256x64 tile, 8 waves (2 x 4), one block per CU, 128 KiB LDS: a rolling LDS-DMA pipeline (guide §5 "8-phase").
-//
-//  * LDS = 2 buffers (K-tile parity) x 4 regions {A0, A1, B0, B1}; a region = 128 rows x 64 k (16 KiB) = one staging
-//    granule = 2 global_load_lds_dwordx4 per thread.  Wave (wr, wc) owns C rows {wr*64..+63} of BOTH A regions and
-//    C columns {wc*32..+31} of BOTH B regions, so each of the 4 phases of a K-tile (one 64x32 quadrant x K=64 =
-//    16 MFMAs per wave) touches ONE A region and ONE B region for every wave:
-//        P0: read A0,B0 -> q(0,0) | P1: read B1 -> q(0,1) | P2: read A1 -> q(1,1) | P3: (B0 frags kept) -> q(1,0)
-//  * every phase stages exactly one granule, 5-6 phases ahead of its first read and >= 2 phases after the last read of
-//    the region it overwrites:   P0: B1(t+1)  P1: A1(t+1)  P2: A0(t+2)  P3: B0(t+2)
-//    so 4 granules (8 LDS-DMA per thread) stay in flight ACROSS barriers: each phase ends with a counted
-//    `s_waitcnt vmcnt(8)` (never 0 in the loop) + ONE raw s_barrier, then its MFMA cluster under s_setprio(1).
-//  * past the last K-tile the stages re-load the last tile into regions nobody reads any more, which keeps the
-//    vmcnt arithmetic uniform (<= 6 wasted granules per block).
-// =================================================================================================================
-constexpr int T256_REGION = 128 * 128;          // bytes
-constexpr int T256_BUF = 4 * T256_REGION;       // A0 A1 B0 B1
-constexpr int T256_SMEM = 256 * (256 * 2 + 16);   // 135168: the two K-tile buffers (131072) / the C staging of the epilogue
-                                                  // (whole bf16 tile, or one 128-row half in f32: 133120)
-
-// Fused RoPE + KV-cache append for the QKV projection (icl_gemm_rope_kv_bf16): the row phase of the staged epilogue.
-// head_dim = 128, so a 256-column tile holds two whole heads of q, of k or of v; the staged tile is bf16, i.e. the
-// rotation sees exactly the values the unfused path would have read back from HBM (same rounding points, rope_rot8).
-struct RopeFuse {
-  const float* cosT;
-  const float* sinT;
-  const int* pos;
-  const int* seq_ids;
-  unsigned short* kc;
-  unsigned short* vc;
-  int k_off, v_off, H, max_len;
-  int kv_rows_to_c;   // 0: k / v go to the cache only (the prefill attention reads them there)
-};
-
-__device__ __forceinline__ void rope_rows(const GemmParams& p, const RopeFuse& rf, const char* smem, int pitch, int m0,
-                                          int n0, int tid) {
-  const int sect = n0 >= rf.v_off ? 2 : (n0 >= rf.k_off ? 1 : 0);
-  const int head0 = (n0 - (sect == 2 ? rf.v_off : sect == 1 ? rf.k_off : 0)) >> 7;
-  unsigned short* C = (unsigned short*)p.C;
-  constexpr int U = 4;
-  if (sect == 2) {   // v: whole rows to the QKV buffer and to the cache
-    for (int base = tid; base < 256 * 32; base += U * 512) {
-      int64_t crow[U];
-      if (rf.vc) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int m = min(m0 + ((base + u * 512) >> 5), p.M - 1);
-          crow[u] = (int64_t)rf.seq_ids[m] * rf.H * rf.max_len + rf.pos[m];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = base + u * 512, row = c >> 5, cc = c & 31, m = m0 + row;
-        if (m >= p.M) continue;
-        const u32x4 v = *(const u32x4*)(smem + row * pitch + cc * 16);
-        if (rf.kv_rows_to_c) *(u32x4*)(C + (int64_t)m * p.ldc + n0 + cc * 8) = v;
-        if (rf.vc) *(u32x4*)(rf.vc + (crow[u] + (int64_t)(head0 + (cc >> 4)) * rf.max_len) * 128 + (cc & 15) * 8) = v;
-      }
-    }
-    return;
-  }
-  const bool to_cache = sect == 1 && rf.kc;
-  for (int base = tid; base < 256 * 16; base += U * 512) {   // items: (row, head-in-tile, 8-column piece of the low half)
-    int ps[U], sq[U];
-    u32x4 lo[U], hi[U];
-    f32x4 c0[U], c1[U], s0[U], s1[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int m = min(m0 + ((base + u * 512) >> 4), p.M - 1);
-      ps[u] = rf.pos[m];
-      sq[u] = to_cache ? rf.seq_ids[m] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int it = base + u * 512, row = it >> 4, hh = (it >> 3) & 1, j = it & 7;
-      const char* src = smem + row * pitch + hh * 256 + j * 16;
-      lo[u] = *(const u32x4*)src;
-      hi[u] = *(const u32x4*)(src + 128);
-      const float* cp = rf.cosT + (int64_t)ps[u] * 64 + j * 8;
-      const float* sp = rf.sinT + (int64_t)ps[u] * 64 + j * 8;
-      c0[u] = *(const f32x4*)cp;
-      c1[u] = *(const f32x4*)(cp + 4);
-      s0[u] = *(const f32x4*)sp;
-      s1[u] = *(const f32x4*)(sp + 4);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int it = base + u * 512, row = it >> 4, hh = (it >> 3) & 1, j = it & 7, m = m0 + row;
-      if (m >= p.M) continue;
-      u32x4 olo, ohi;
-      rope_rot8(lo[u], hi[u], c0[u], c1[u], s0[u], s1[u], olo, ohi);
-      if (sect == 0 || rf.kv_rows_to_c) {
-        unsigned short* dst = C + (int64_t)m * p.ldc + n0 + hh * 128 + j * 8;
-        *(u32x4*)dst = olo;
-        *(u32x4*)(dst + 64) = ohi;
-      }
-      if (to_cache) {
-        unsigned short* cd = rf.kc + (((int64_t)sq[u] * rf.H + head0 + hh) * rf.max_len + ps[u]) * 128 + j * 8;
-        *(u32x4*)cd = olo;
-        *(u32x4*)(cd + 64) = ohi;
-      }
-    }
-  }
-}
-
-template <bool ROPE>
-__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p, RopeFuse rf) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  int tm, tn;
-  block_to_tile(p, blockIdx.x, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int z = blockIdx.z;
-  const __bf16* A = p.A + (int64_t)z * p.sA;
-  const int nk = p.K >> 6;
-
-  // ---- staging sources: region h, round r -> rows 8*(r*8 + wave) + (lane>>3) of the region -------------------
-  const __bf16* gsrc[2][2][2];  // [A|B][region][round]
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int row = (r * 8 + wave) * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      gsrc[0][h][r] = A + (int64_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + chunk * 8;
-      gsrc[1][h][r] = p.W + (int64_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + chunk * 8;
-    }
-  auto stage = [&](int bo, int which, int h, int kt) {   // bo: byte offset of the K-tile buffer (0 | T256_BUF); which: 0 = A, 1 = B
-    const int64_t koff = (int64_t)min(kt, nk - 1) * 64;
-    char* base = smem + bo + (which * 2 + h) * T256_REGION + wave * 1024;
-    __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[which][h][0] + koff), (lptr_t)(base), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[which][h][1] + koff), (lptr_t)(base + 8 * 1024), 16, 0, 0);
-  };
-
-  // ---- fragment read offsets -------------------------------------------------------------------------------------
-  const int fr = lane & 15, fq = lane >> 4;
-  const int a_base = (wr * 64 + fr) * 128, b_base = (wc * 32 + fr) * 128;
-  const int sw0 = ((0 + fq) ^ (fr >> 1)) * 16, sw1 = ((4 + fq) ^ (fr >> 1)) * 16;
-
-  f32x4 acc[2][2][4][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
-  const bool vecp = vec_path_ok(p);
-  const bool interior = vecp && (m0 + 256 <= p.M) && (n0 + 256 <= p.N);
-  const bool fold_bias = vecp && (p.epi & ICL_EPI_BIAS);
-  // the residual is added LAST, (bias + sum) + r, in every kernel and every tile (interior, edge, any tile shape): the order
-  // is part of the batch-invariance contract; the 256x256 kernel reads it as whole rows in its LDS-staged epilogue
-  constexpr bool fold_res = false;
-
-  auto read_a = [&](int bo, int h) {
-    const char* r = smem + bo + h * T256_REGION + a_base;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      af[i][0] = *(const bf16x8*)(r + i * 2048 + sw0);
-      af[i][1] = *(const bf16x8*)(r + i * 2048 + sw1);
-    }
-  };
-  auto read_b = [&](int bo, int h, bf16x8 (&bf)[2][2]) {
-    const char* r = smem + bo + (2 + h) * T256_REGION + b_base;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bf[j][0] = *(const bf16x8*)(r + j * 2048 + sw0);
-      bf[j][1] = *(const bf16x8*)(r + j * 2048 + sw1);
-    }
-  };
-  // MFMA cluster of one phase, closed by the phase's SECOND barrier.  The two wave groups (wr = 0 / 1) run one barrier
-  // apart (see the stagger below), so between two consecutive barriers one group issues its 16 MFMAs while the other
-  // issues its LDS reads + LDS-DMA + waits: matrix pipe and LDS/VMEM overlap on every SIMD (2 waves/SIMD, one per group).
-  auto mma = [&](f32x4 (&c)[4][2], bf16x8 (&bf)[2][2]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], c[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // the phase's counted wait (N = LDS-DMA instructions that may stay in flight: 8 = four granules in steady state) + barrier
-  auto phase_sync = [&](auto n_tag) {
-    constexpr int N = decltype(n_tag)::value;
-    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // MODE 0: steady state (every phase stages one granule 5-6 phases ahead, vmcnt(8)); bo / bo ^ T256_BUF = this / the other
-  // K-tile buffer.  MODE 1 / 2: K-tiles nk-2 / nk-1: stage-ahead targets past the end of K are NOT issued (no dummy re-loads,
-  // no drain before the block retires); each wait lets exactly the instructions issued in the last four phases stay in
-  // flight, which shrinks 8 -> 6 -> 4 -> 2 -> 0 as the staging runs dry, so the guarantee "the granule staged four phases
-  // ago has landed" is the one of the steady state.
-  auto tile = [&](int bo, int t, auto mode) {
-    constexpr int MODE = decltype(mode)::value;
-    const int bx = bo ^ T256_BUF;
-    // P0
-    read_a(bo, 0);
-    read_b(bo, 0, b0f);
-    if constexpr (MODE != 2) stage(bx, 1, 1, t + 1);
-    phase_sync(std::integral_constant<int, MODE == 2 ? 2 : 8>{});
-    mma(acc[0][0], b0f);
-    // P1
-    read_b(bo, 1, b1f);
-    if constexpr (MODE != 2) stage(bx, 0, 1, t + 1);
-    phase_sync(std::integral_constant<int, MODE == 2 ? 0 : 8>{});
-    mma(acc[0][1], b1f);
-    // P2
-    read_a(bo, 1);
-    if constexpr (MODE == 0) stage(bo, 0, 0, t + 2);
-    phase_sync(std::integral_constant<int, MODE == 0 ? 8 : (MODE == 1 ? 6 : 0)>{});
-    mma(acc[1][1], b1f);
-    // P3
-    if constexpr (MODE == 0) stage(bo, 1, 0, t + 2);
-    phase_sync(std::integral_constant<int, MODE == 0 ? 8 : (MODE == 1 ? 4 : 0)>{});
-    mma(acc[1][0], b0f);
-  };
-  using M0_ = std::integral_constant<int, 0>;
-  using M1_ = std::integral_constant<int, 1>;
-  using M2_ = std::integral_constant<int, 2>;
-
-  // accumulator init = (f32 residual) + bias: pure loads issued BEFORE the prologue's LDS-DMA, first use after it;
-  // tile-independent decision (vec_path_ok), edge tiles only add bounds guards
-  f32x4 bias_f[2][2];
-  if (fold_res) {
-#pragma unroll
-    for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int m = m0 + qa * 128 + wr * 64 + i * 16 + fr, n = n0 + qb * 128 + wc * 32 + j * 16 + fq * 4;
-            if (interior || (m < p.M && n < p.N))
-              acc[qa][qb][i][j] = *(const f32x4*)((const float*)p.R + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
-          }
-  }
-  if (fold_bias) {
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + qb * 128 + wc * 32 + j * 16 + fq * 4;
-        bias_f[qb][j] = (interior || n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-  }
-  // prologue: A0(0) B0(0) B1(0) A1(0) A0(1) B0(1), then the uniform wait
-  __builtin_amdgcn_sched_barrier(0);
-  stage(0, 0, 0, 0);
-  stage(0, 1, 0, 0);
-  stage(0, 1, 1, 0);
-  stage(0, 0, 1, 0);
-  stage(T256_BUF, 0, 0, 1);
-  stage(T256_BUF, 1, 0, 1);
-  __builtin_amdgcn_sched_barrier(0);
-  if (fold_bias) {   // first use of the pre-loaded operands: ONE wait covers loads and prologue
-#pragma unroll
-    for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[qa][qb][i][j] = acc[qa][qb][i][j] + bias_f[qb][j];
-  }
-  phase_sync(std::integral_constant<int, 8>{});
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0 (hazard analysis in DESIGN.md §4)
-  // K-tiles 0 .. nk-3 in steady state (compile-time buffers), then the two tail K-tiles on a run-time buffer offset (the host
-  // sends K < 128 to the other tiles: nk >= 2 here)
-  const int n_steady = nk - 2;
-  int t = 0;
-  for (; t + 1 < n_steady; t += 2) {
-    tile(0, t, M0_{});
-    tile(T256_BUF, t + 1, M0_{});
-  }
-  if (t < n_steady) {
-    tile(0, t, M0_{});
-    ++t;
-  }
-  const int bo = (t & 1) ? T256_BUF : 0;
-  tile(bo, t, M1_{});
-  tile(bo ^ T256_BUF, t + 1, M2_{});
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count of the two groups
-
-  // ---- interior tiles: the C tile leaves through LDS ---------------------------------------------------------------
-  // An MFMA fragment gives a lane 4 consecutive columns of ONE row, so direct stores are 8-B (bf16) pieces in 32-B row
-  // segments: 32 partial-line stores per thread, measured at 6.4 us per tile (21 % of a K = 1280 tile, 6 % at K = 4096; the
-  // same kernel without its stores runs 1.39 PF/s at K = 1280).  The K-tile buffers are dead after the main loop, so each
-  // 128-row half of the tile is written to LDS in its output type (row pitch + 16 B: conflict-free for both the fragment
-  // writes and the row reads) and read back as whole rows, 16 B per lane, full cache lines per wave-instruction.
-  const int es_out = p.out_dtype == ICL_BF16 ? 2 : 4;
-  const bool rows16 = (((uintptr_t)p.C | (uintptr_t)(p.ldc * es_out) | (uintptr_t)(p.sC * es_out)) & 15) == 0;   // whole rows in 16-B pieces
-  const bool has_res = p.epi & ICL_EPI_RESIDUAL;
-  const bool res_rows = has_res && p.res_dtype == ICL_F32 && p.out_dtype == ICL_F32 && !(p.epi & ICL_EPI_SWIGLU) &&
-                        (((uintptr_t)p.R | (uintptr_t)(p.ldr * 4) | (uintptr_t)(p.sR * 4)) & 15) == 0;
-  if (ROPE || (interior && rows16 && (!has_res || res_rows))) {   // ROPE: the host has checked the layout; row-masked M edge
-    const bool swiglu = p.epi & ICL_EPI_SWIGLU;
-    const bool obf = p.out_dtype == ICL_BF16;
-    const int out_cols = swiglu ? 128 : 256;
-    const int es = obf ? 2 : 4;
-    const int pitch = out_cols * es + 16;                        // bytes per staged row
-    const int chunks_per_row = out_cols * es / 16;               // 16-B pieces per row: 16 | 32 | 64
-    const int64_t c_col0 = swiglu ? (n0 >> 1) : n0;
-    const bool one_round = ROPE || obf;                          // a bf16 tile fits whole: two barriers instead of four (two rounds
-                                                                 // under GELU, to drain stores behind the second half's VALU work: no gain)
-#pragma unroll
-    for (int qa = 0; qa < 2; ++qa) {
-      if (qa == 0 || !one_round) __syncthreads();                // K-tile reads (qa = 0) / the previous half's row reads are done
-      const int row_off = one_round ? qa * 128 : 0;
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = row_off + wr * 64 + i * 16 + fr;
-          if (swiglu) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = silu_f(acc[qa][qb][i][0][r]) * acc[qa][qb][i][1][r];
-            const int col = qb * 64 + wc * 16 + fq * 4;
-            char* dst = smem + row * pitch + col * es;
-            if (obf) *(u32x2*)dst = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            else *(f32x4*)dst = v;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              f32x4 v = acc[qa][qb][i][j];
-              if (p.epi & ICL_EPI_GELU) {
-            v = gelu_erf4(v);
-              }
-              const int col = qb * 128 + wc * 32 + j * 16 + fq * 4;
-              char* dst = smem + row * pitch + col * es;
-              if (obf) *(u32x2*)dst = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-              else *(f32x4*)dst = v;
-            }
-          }
-        }
-      if (one_round && qa == 0) continue;
-      __syncthreads();
-      if constexpr (ROPE) {   // (not a return: an early exit inside the qa loop keeps hipcc from unrolling it -> acc in scratch)
-        rope_rows(p, rf, smem, pitch, m0, n0, tid);
-        continue;
-      }
-      char* cbase = (char*)p.C + ((int64_t)z * p.sC + (int64_t)(m0 + (one_round ? 0 : qa * 128)) * p.ldc + c_col0) * es;
-      const int n_chunks = (one_round ? 256 : 128) * chunks_per_row;   // a multiple of the 512 threads
-      if (has_res) {   // f32 residual stream: whole-row 16-B loads, all of a thread's 16 issued before the first use
-        const char* rbase = (const char*)p.R + ((int64_t)z * p.sR + (int64_t)(m0 + qa * 128) * p.ldr + n0) * 4;
-        f32x4 rr[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int c = tid + it * 512, row = c >> 6, cc = c & 63;
-          rr[it] = *(const f32x4*)(rbase + (int64_t)row * p.ldr * 4 + cc * 16);
-        }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int c = tid + it * 512, row = c >> 6, cc = c & 63;
-          const f32x4 v = *(const f32x4*)(smem + row * pitch + cc * 16) + rr[it];
-          *(f32x4*)(cbase + (int64_t)row * p.ldc * 4 + cc * 16) = v;
-        }
-      } else {
-        for (int c = tid; c < n_chunks; c += 512) {
-          const int row = c / chunks_per_row, cc = c - row * chunks_per_row;
-          const u32x4 v = *(const u32x4*)(smem + row * pitch + cc * 16);
-          *(u32x4*)(cbase + (int64_t)row * p.ldc * es + cc * 16) = v;
-        }
-      }
-    }
-    return;
-  } else if (interior) {
-    const bool late_res = (p.epi & ICL_EPI_RESIDUAL) && !fold_res;
-#pragma unroll
-    for (int qa = 0; qa < 2; ++qa) {
-      const int mb = m0 + qa * 128 + wr * 64 + fr;
-      if (p.epi & ICL_EPI_SWIGLU) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int qb = 0; qb < 2; ++qb) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = silu_f(acc[qa][qb][i][0][r]) * acc[qa][qb][i][1][r];
-            store_out4(p, (int64_t)z * p.sC + (int64_t)(mb + i * 16) * p.ldc + ((n0 + qb * 128 + wc * 32) >> 1) + fq * 4, v);
-          }
-        continue;
-      }
-      f32x4 rv[2][4][2];
-      if (late_res) {   // one batch of 16 independent loads per half tile
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              rv[qb][i][j] = load_res4(p, (int64_t)z * p.sR + (int64_t)(mb + i * 16) * p.ldr + n0 + qb * 128 + wc * 32 + j * 16 + fq * 4);
-      }
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            f32x4 v = acc[qa][qb][i][j];
-            if (p.epi & ICL_EPI_GELU) {
-            v = gelu_erf4(v);
-            }
-            if (late_res) v = v + rv[qb][i][j];
-            store_out4(p, (int64_t)z * p.sC + (int64_t)(mb + i * 16) * p.ldc + n0 + qb * 128 + wc * 32 + j * 16 + fq * 4, v);
-          }
-    }
-    return;
-  }
-
-  // ---- edge tiles: same arithmetic, bounds-checked stores; operands already folded are not re-applied ----------------
-  GemmParams q = p;
-  if (fold_bias) q.epi &= ~ICL_EPI_BIAS;
-  if (fold_res) q.epi &= ~ICL_EPI_RESIDUAL;
-#pragma unroll
-  for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + qa * 128 + wr * 64 + i * 16 + fr;
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const int nt = n0 + qb * 128 + wc * 32;
-        if (p.epi & ICL_EPI_SWIGLU) {
-          epi_store_swiglu(q, z, m, nt, fq * 4, acc[qa][qb][i][0], acc[qa][qb][i][1]);
-        } else {
-          epi_store4(q, z, m, nt + fq * 4, acc[qa][qb][i][0]);
-          epi_store4(q, z, m, nt + 16 + fq * 4, acc[qa][qb][i][1]);
-        }
-      }
-    }
-}
-
-int launch_tile256(GemmParams& p, int batch, hipStream_t stream, const RopeFuse* rope = nullptr) {
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_SMEM);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)gemm256_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T256_SMEM);
-    if (e != hipSuccess) {
-      icl_set_error("icl_gemm_bf16: hipFuncSetAttribute(%d) failed: %s", T256_SMEM, hipGetErrorString(e));
-      return ICL_ELAUNCH;
-    }
-    attr_set = true;
-  }
-  const dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
-  if (rope)
-    hipLaunchKernelGGL(gemm256_bf16_kernel<true>, grid, dim3(512), T256_SMEM, stream, p, *rope);
-  else
-    hipLaunchKernelGGL(gemm256_bf16_kernel<false>, grid, dim3(512), T256_SMEM, stream, p, RopeFuse{});
-  ICL_CHECK_LAUNCH("icl_gemm_bf16(256)");
-  return ICL_OK;
-}
 
 
 // =================================================================================================================

@@ -200,7 +200,7 @@ def run_inference(args) -> Dict[str, Any]:
         eos_id = getattr(_tokenizer_of(model), "eos_token_id", None)
         rows: Dict[int, Dict[str, Any]] = {}         # dataset index -> record (strings) of THIS rank
         ids_l, len_l, logit_l, idx_l = [], [], [], []
-        failed_batches = 0
+        failed_batches = failed_rows = 0
         with torch.no_grad():
             for batch_idx, batch in enumerate(device_prefetch(loader, args.device)):      # batch i+1's H2D under batch i's kernels
                 n_b = len(batch["prompt"])
@@ -211,18 +211,26 @@ def run_inference(args) -> Dict[str, Any]:
                     res = model.generate_ids(batch, want_first_logits=True)
                     outputs = model.decode_ids(res.tokens)
                     dt = time.time() - t0
+                    # rows the model could not run (prompt over max_pos) cost their own utterance only: they are left out of
+                    # every list below and surface as missing indices, the other rows of the batch proceed
+                    dropped = set(getattr(res, "dropped", ()) or ())
+                    keep = [i for i in range(n_b) if i not in dropped]
+                    if dropped:
+                        failed_rows += len(dropped)
+                        logger.error("Error processing dataset indices %s of batch %d: prompt + new tokens exceed the model's "
+                                     "max_pos", [b_idx[i] for i in sorted(dropped)], batch_idx)
                     toks = torch.full((n_b, args.max_new_tokens), pad_id, dtype=torch.int32)
                     toks[:, :res.tokens.shape[1]] = res.tokens.to(torch.int32)
-                    ids_l.append(toks)
-                    len_l.append(_generated_lengths(res.tokens, eos_id))
-                    logit_l.append(res.first_logits[:, label_ids].to(torch.bfloat16).cpu())
-                    idx_l.extend(b_idx)
-                    for i, (out, true_label) in enumerate(zip(outputs, batch["completion"])):
-                        dt_i = batch["dataset_type"][i]
+                    ids_l.append(toks[keep])
+                    len_l.append(_generated_lengths(res.tokens, eos_id)[keep])
+                    logit_l.append(res.first_logits[:, label_ids].to(torch.bfloat16).cpu()[keep])
+                    idx_l.extend(b_idx[i] for i in keep)
+                    for i in keep:
+                        out, true_label, dt_i = outputs[i], batch["completion"][i], batch["dataset_type"][i]
                         rows[b_idx[i]] = {"text": batch["text"][i], "true_label": true_label,
                                           "predicted_label (cleaned)": clean_prediction(out, dt_i),
                                           "predicted_label": out.strip(), "dataset_type": DatasetType(dt_i).value}
-                    tracker.update(dt, len(batch["input_ids"]))
+                    tracker.update(dt, len(keep))
                 except (torch.cuda.OutOfMemoryError, IclError):
                     raise        # device-side failures are not "a bad sample": stop with a non-zero exit code
                 except Exception as e:   # a failed batch is logged and skipped, as in the reference (:370-373)
@@ -231,7 +239,7 @@ def run_inference(args) -> Dict[str, Any]:
                     logger.debug(traceback.format_exc())
                     continue
         perf = tracker.get_summary()
-        perf["failed_batches"] = failed_batches
+        perf["failed_batches"], perf["failed_rows"] = failed_batches, failed_rows
         if world > 1:
             # ONE fixed-shape all-gather of (index, gen_ids, gen_len, first-step label logits) + one of the UTF-8 string side;
             # rank 0 re-orders by DATASET INDEX, so a batch dropped on one rank shows up as missing indices, never as a shift.

@@ -254,7 +254,11 @@ class CustomQwen(BaseModel):
                                     do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),
                                     top_p=float(g.get("top_p", 1.0)), top_k=int(g.get("top_k", 50)),
                                     repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"),
-                                    want_first_logits=want_first_logits)
+                                    want_first_logits=want_first_logits, overlong="drop")
+        self.last_dropped_rows = tuple(res.dropped)      # rows over max_pos cost their own utterance only (see CustomSALMONN)
+        if res.dropped:
+            logger.error("rows %s of this batch were not generated: prompt + new tokens exceed max_pos %d", list(res.dropped),
+                         self.cfg.llm.max_pos)
         self.batch_counter += 1
         return res
 

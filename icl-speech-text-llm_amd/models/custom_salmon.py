@@ -530,7 +530,14 @@ class CustomSALMONN(BaseModel):
                                     temperature=float(samples.get("temperature", 0.8)), top_p=float(samples.get("top_p", 0.9)),
                                     top_k=int(samples.get("top_k", 50)),
                                     repetition_penalty=float(samples.get("repetition_penalty", 1.0)),
-                                    generator=samples.get("generator"), want_first_logits=want_first_logits)
+                                    generator=samples.get("generator"), want_first_logits=want_first_logits,
+                                    overlong="drop")
+        # a prompt over max_pos costs ITS utterance, not the batch (the reference runs batch 1: inference/inference.py:370-373);
+        # such rows come back pad-filled and are listed here for the caller (the CLI reports them as missing indices)
+        self.last_dropped_rows = tuple(res.dropped)
+        if res.dropped:
+            logger.error("rows %s of this batch were not generated: prompt + new tokens exceed max_pos %d", list(res.dropped),
+                         self.runtime.lm_cfg.max_pos)
         # host-side stage times of the last batch (launch of the speech encoders / prompt split + tokenisation / decoder incl.
         # the wait for the ids): the encoders run asynchronously under the tokenisation
         self.last_stage_seconds = {"speech_launch": t1 - t0, "segments": t2 - t1, "generate": time.perf_counter() - t2}

@@ -62,7 +62,7 @@ class LlamaCfg:
     vocab: int = 32001        # 32000 + the [PAD] token SALMONN adds (SURVEY.md §7 "quirks")
     rms_eps: float = 1e-5
     rope_theta: float = 10000.0
-    max_pos: int = 2048
+    max_pos: int = 4096       # Llama-2 (max_position_embeddings); HF-folder ingestion overrides it from config.json
     bos_id: int = 1
     eos_id: int = 2
     pad_id: int = 32000

@@ -33,6 +33,7 @@ class GenerateResult:
     tokens: torch.Tensor          # int64 [B, width] on CPU — what HF generate() returns with inputs_embeds
     first_logits: Optional[torch.Tensor] = None  # f32 [B, V] (device) logits of the first generated position
     step_logits: Optional[torch.Tensor] = None   # f32 [max_new_tokens, B, V] (device): the logits every token was chosen from
+    dropped: Tuple[int, ...] = ()                # rows NOT generated (``overlong="drop"``): pad-filled tokens, NaN logits
 
 
 class CausalLMRuntimeMixin:
@@ -67,6 +68,12 @@ class CausalLMRuntimeMixin:
                 raise ValueError("empty prompt")
             lens.append(len(flat) - before)
         return flat, lens
+
+    @staticmethod
+    def _prompt_lengths(prompts: Sequence[Sequence[Segment]]) -> List[int]:
+        """Positions per prompt (host arithmetic only; the validation of ``generate`` runs before anything is launched)."""
+        return [sum(seg[2] if (isinstance(seg, tuple) and len(seg) == 3 and seg[0] == "speech") else len(seg) for seg in segs)
+                for segs in prompts]
 
     def embed_prompts(self, prompts, speech: Optional[torch.Tensor], name: str = "ll_h"):
         rows = 0 if speech is None else speech.shape[0] * (speech.shape[1] if speech.dim() == 3 else 1)
@@ -118,7 +125,7 @@ class CausalLMRuntimeMixin:
                  pad_id: Optional[int] = None, suppress_eos: bool = False, want_first_logits: bool = False,
                  cache_len_multiple: int = 64, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
                  top_k: int = 50, repetition_penalty: float = 1.0, generator: Optional[torch.Generator] = None,
-                 sample_debug=None, want_step_logits: bool = False) -> GenerateResult:
+                 sample_debug=None, want_step_logits: bool = False, overlong: str = "raise") -> GenerateResult:
         """Greedy search with HF ``generate(inputs_embeds=…)`` semantics (models/custom_salmon.py:704-720): returns only
         the new tokens; a row that has emitted EOS is filled with pad; the width is that of the longest row
         (``min_length`` is a no-op with inputs_embeds).  All steps are enqueued without a host sync; the
@@ -128,8 +135,39 @@ class CausalLMRuntimeMixin:
         top-k → top-p → draw; ``temperature`` / ``top_p`` / ``top_k`` are ignored otherwise, as in HF); a repetition penalty
         ≠ 1 in greedy mode runs the same kernel with ``top_k = 1``.  The draws are uniforms from ``generator`` (a device
         generator; default: torch's global CUDA generator): reproducible for a seed, not bit-identical to
-        ``torch.multinomial``."""
+        ``torch.multinomial``.
+
+        ``overlong``: a row whose prompt + ``max_new_tokens`` exceeds ``max_pos`` is validated on the host BEFORE any launch.
+        ``"raise"`` (default) fails the call; ``"drop"`` generates the other rows and reports the row in ``dropped`` (its
+        tokens are pad, its logits NaN) — the reference runs batch 1, where one over-long prompt costs one utterance
+        (inference/inference.py:370-373), not the batch it happens to be collated with."""
         c, ws, dev = self.lm_cfg, self.ws, self.device
+        if overlong not in ("raise", "drop"):
+            raise ValueError(f"overlong must be 'raise' or 'drop', not {overlong!r}")
+        limit = c.max_pos // cache_len_multiple * cache_len_multiple      # cache lengths are multiples of cache_len_multiple
+        plens = self._prompt_lengths(prompts)
+        bad = [b for b, n in enumerate(plens) if n + max_new_tokens > limit]
+        if bad and (overlong == "raise" or len(bad) == len(plens)):
+            raise ValueError(f"prompt + new tokens of row(s) {bad} ({[plens[b] + max_new_tokens for b in bad]} positions) "
+                             f"exceed max_pos {c.max_pos}")
+        if bad:
+            keep = [b for b in range(len(plens)) if b not in set(bad)]
+            sub = self.generate([prompts[b] for b in keep], speech, max_new_tokens=max_new_tokens, eos_id=eos_id, pad_id=pad_id,
+                                suppress_eos=suppress_eos, want_first_logits=want_first_logits,
+                                cache_len_multiple=cache_len_multiple, do_sample=do_sample, temperature=temperature, top_p=top_p,
+                                top_k=top_k, repetition_penalty=repetition_penalty, generator=generator,
+                                sample_debug=sample_debug, want_step_logits=want_step_logits)
+            n, kidx = len(plens), torch.tensor(keep)
+            toks = torch.full((n, sub.tokens.shape[1]), c.pad_id if pad_id is None else pad_id, dtype=torch.int64)
+            toks[kidx] = sub.tokens
+            first = steps = None
+            if sub.first_logits is not None:
+                first = torch.full((n, sub.first_logits.shape[1]), float("nan"), dtype=F32, device=dev)
+                first[kidx.to(dev)] = sub.first_logits
+            if sub.step_logits is not None:
+                steps = torch.full((sub.step_logits.shape[0], n, sub.step_logits.shape[2]), float("nan"), dtype=F32, device=dev)
+                steps[:, kidx.to(dev)] = sub.step_logits
+            return GenerateResult(tokens=toks, first_logits=first, step_logits=steps, dropped=tuple(bad))
         eos = c.eos_id if eos_id is None else eos_id
         pad = c.pad_id if pad_id is None else pad_id
         if suppress_eos:
@@ -139,7 +177,7 @@ class CausalLMRuntimeMixin:
         Bn = len(lens)
         need = max(lens) + max_new_tokens
         max_len = -(-need // cache_len_multiple) * cache_len_multiple
-        assert max_len <= c.max_pos, f"prompt + new tokens ({need}) exceeds max_pos {c.max_pos}"
+        assert max_len <= c.max_pos, f"prompt + new tokens ({need}) exceeds max_pos {c.max_pos}"   # validated above
         cache = self._cache(Bn, max_len)
         marks = getattr(self, "phase_marks", None)     # optional {name: torch.cuda.Event}: bench.py times prefill / decode with it
         if marks is not None:

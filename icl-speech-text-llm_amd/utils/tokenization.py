@@ -13,6 +13,7 @@ from __future__ import annotations
 import logging
 import os
 import re
+import zlib
 from typing import List, Sequence, Union
 
 import torch
@@ -96,35 +97,78 @@ class ByteTokenizer:
         return [self.decode(row, skip_special_tokens=skip_special_tokens) for row in batch]
 
 
+def _task_table_strings():
+    """Every string of the shipped task tables (prompt templates, label sets, label mappings): the text the benchmark and the
+    CLI tokenise over and over, and the labels whose first-token ids index the gathered logits."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "task_prompts.json")
+    try:
+        with open(path, encoding="utf-8") as f:
+            table = json.load(f)
+    except OSError:
+        return
+    stack = [table]
+    while stack:
+        o = stack.pop()
+        if isinstance(o, str):
+            yield o
+        elif isinstance(o, dict):
+            stack.extend(o.keys())
+            stack.extend(o.values())
+        elif isinstance(o, (list, tuple)):
+            stack.extend(o)
+
+
 class SubwordStandInTokenizer(ByteTokenizer):
     """Offline stand-in with the TOKEN COUNT of a sentencepiece Llama tokenizer (~3.9 characters per token on the
     reference's English prompts) rather than one token per byte: text is cut into space-prefixed word pieces
-    of at most ``piece`` characters (5: 286 / 502 / 330 tokens on the VoxCeleb / HVB / VoxPopuli 5-shot prompts against the survey's 288 / 512 / 320), and each distinct piece gets the next free id (259 .. vocab-2) the first time it is
-    seen, so ``decode`` inverts ``encode`` within one process.  It is NOT a real vocabulary — it exists so that benchmark
-    prompts through the plugin have the prompt length the frozen workload definition assumes (376 positions for C2) when no
-    tokenizer files are reachable; select it with ``llama_path="stand-in:subword"``."""
+    of at most ``piece`` characters (5: 286 / 502 / 330 tokens on the VoxCeleb / HVB / VoxPopuli 5-shot prompts against the
+    survey's 288 / 512 / 320).
+
+    ``encode`` is a PURE FUNCTION of the text — the same ids in every process, rank and DataLoader worker (ranks exchange
+    generated ids and label-logit columns, rank 0 decodes everybody's rows):
+      * a fixed base vocabulary, built at construction from the shipped task tables (every piece of every prompt template
+        and label, with and without a leading space, in sorted order) takes ids 259 ..; those always decode exactly;
+      * any other piece takes ``base_end + crc32(piece) mod (free ids)``.  Two pieces may share such an id (a stand-in, not
+        a vocabulary), so ``decode`` renders hashed ids as nothing — in EVERY process, whether or not it has encoded such a
+        piece: decoding is a pure function of the ids too (only a random-weight model emits them; label words are base
+        pieces).
+    It exists so that benchmark prompts through the plugin have the prompt length the frozen workload definition assumes
+    (376 positions for C2) when no tokenizer files are reachable; select it with ``llama_path="stand-in:subword"``."""
 
     def __init__(self, vocab_size: int = 32001, piece: int = 5):
         super().__init__(vocab_size)
         self.piece = piece
-        self._ids, self._pieces = {}, {}
         self._split = re.compile(r"(?s).[^ \n]{0,%d}" % (piece - 1)).findall
+        base = set()
+        for text in _task_table_strings():
+            base.update(self._split(text))
+            base.update(self._split(" " + text))
+        room = max(0, (self._vocab - 1 - 259) // 2)              # at most half of the free ids; the rest is the hashed range
+        self._ids = {p: 259 + i for i, p in enumerate(sorted(base)[:room])}
+        self._pieces = {t: p for p, t in self._ids.items()}
+        self._hash0 = 259 + len(self._ids)
+        self._hash_n = self._vocab - 1 - self._hash0             # ids _hash0 .. vocab-2 (vocab-1 = [PAD])
+
+    def _id_of(self, p: str) -> int:
+        t = self._ids.get(p)
+        if t is None:
+            if self._hash_n <= 0:
+                return -1
+            t = self._ids[p] = self._hash0 + zlib.crc32(p.encode("utf-8")) % self._hash_n      # memo only: never inverted
+        return t
 
     def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
         out: List[int] = [self.bos_token_id] if add_special_tokens else []
-        ids = self._ids
         # a piece = one character (of any kind) + up to piece-1 following characters that are neither space nor newline, so
         # it never crosses a word boundary; one regex pass instead of a per-character loop (128 prompts of ~1500 characters
         # per batch sit on the host path of the plugin benchmark)
         for p in self._split(text):
-            t = ids.get(p)
-            if t is None:
-                t = 259 + len(ids)
-                if t >= self._vocab - 1:                  # vocabulary exhausted: fall back to bytes for this piece
-                    out.extend(b + 3 for b in p.encode("utf-8"))
-                    continue
-                ids[p], self._pieces[t] = t, p
-            out.append(t)
+            t = self._id_of(p)
+            if t < 0:                                             # no id range at all (tiny vocabularies): bytes
+                out.extend(b + 3 for b in p.encode("utf-8"))
+            else:
+                out.append(t)
         return out
 
     def decode(self, ids, skip_special_tokens: bool = False, **_) -> str:

@@ -115,19 +115,33 @@ from icl_speech_text_llm_amd.inference.inference import run_inference, parse_arg
 from icl_speech_text_llm_amd.runtime.salmonn import GenerateResult
 import icl_speech_text_llm_amd.models.custom_salmon as cs
 
+if os.environ.get("DP_STANDIN") == "1":
+    # the offline sub-word stand-in tokenizer (what the benchmark and the offline CLI run with): every process first
+    # tokenises DIFFERENT text, so ids handed out in first-seen order (the round-2 form) would differ between ranks
+    from icl_speech_text_llm_amd.utils.tokenization import SubwordStandInTokenizer
+    def _standin(path, vocab_size=32001):
+        tok = SubwordStandInTokenizer(32001)
+        tok.encode(" ".join(f"warm{os.environ.get('RANK', '0')}x{i}" for i in range(50)))
+        return tok
+    cs.load_llama_tokenizer = _standin
+
 def fake_generate_ids(self, samples, want_first_logits=False):
     # CPU stand-in for the HIP generate: a deterministic function of the prompt (tests the DP plumbing only)
+    if os.environ.get("DP_DROP") == "1" and int(os.environ.get("RANK", "0")) == 0 and self.batch_counter == 1:
+        drop = (1,)          # row 1 of rank 0's second batch "exceeds max_pos": the other row of the batch must survive
+    else:
+        drop = ()
     if os.environ.get("DP_FAIL") == "1" and int(os.environ.get("RANK", "0")) == 1 and self.batch_counter == 1:
         self.batch_counter += 1
         raise ValueError("injected failure of rank 1's second batch")
-    tok, V = self.llama_tokenizer, self.cfg.llama.vocab
+    tok, V = self.llama_tokenizer, max(self.cfg.llama.vocab, len(self.llama_tokenizer))
     rows = [tok(f"neutral {len(p) % 7}", add_special_tokens=False, return_tensors="pt")["input_ids"].reshape(-1).tolist()
             + [tok.eos_token_id] for p in samples["prompt"]]
     w = max(len(r) for r in rows)
     toks = torch.tensor([r + [tok.pad_token_id] * (w - len(r)) for r in rows], dtype=torch.int64)
     first = torch.stack([torch.arange(V, dtype=torch.float32) * 0.25 + (len(p) % 13) for p in samples["prompt"]])
     self.batch_counter += 1
-    return GenerateResult(tokens=toks, first_logits=first)
+    return GenerateResult(tokens=toks, first_logits=first, dropped=drop)
 cs.CustomSALMONN.generate_ids = fake_generate_ids
 args = parse_args(["--peft_model_path", "", "--run_name", "dp", "--dataset_type", "voxceleb-hvb", "--device", "cpu",
                    "--arch", "tiny", "--synthetic_items", "5", "--batch_size", "2", "--num_workers", "0",
@@ -137,7 +151,8 @@ if int(os.environ["RANK"]) == 0:
     json.dump({"n": len(out["results"]), "texts": [r["text"] for r in out["results"]],
                "preds": [r["predicted_label"] for r in out["results"]],
                "label_logits": out["label_logits"],
-               "missing": out["performance"]["missing_indices"], "failed": out["performance"]["failed_batches"]},
+               "missing": out["performance"]["missing_indices"], "failed": out["performance"]["failed_batches"],
+               "failed_rows": out["performance"]["failed_rows"]},
               open(os.path.join(sys.argv[2], "summary.json"), "w"))
 """
 
@@ -162,7 +177,7 @@ def test_data_parallel_sharding_gloo_world2(tmp_path):
     failing on rank 1 the surviving records keep their places and the lost indices are reported, not shifted over."""
     script = tmp_path / "dp.py"
     script.write_text(_DP_SCRIPT)
-    for d in ("w1", "w2", "w2f", "w3"):
+    for d in ("w1", "w2", "w2f", "w3", "w2d", "s1", "s2"):
         (tmp_path / d).mkdir()
     a = _run_dp(script, tmp_path / "w1", 1, 0)
     b = _run_dp(script, tmp_path / "w2", 2, 29611)
@@ -177,6 +192,18 @@ def test_data_parallel_sharding_gloo_world2(tmp_path):
     assert c["failed"] == 1 and c["missing"] == [5, 7] and c["n"] == 8     # rank 1 holds 1,3,5,7,9: its 2nd batch is (5, 7)
     keep = [i for i in range(10) if i not in (5, 7)]
     assert c["texts"] == [a["texts"][i] for i in keep] and c["preds"] == [a["preds"][i] for i in keep]
+    # one ROW over max_pos (GenerateResult.dropped) costs that utterance only: rank 0 holds 0,2,4,6,8, its 2nd batch is (4, 6)
+    e = _run_dp(script, tmp_path / "w2d", 2, 29617, {"DP_DROP": "1"})
+    assert e["failed"] == 0 and e["failed_rows"] == 1 and e["missing"] == [6] and e["n"] == 9
+    keep = [i for i in range(10) if i != 6]
+    assert e["texts"] == [a["texts"][i] for i in keep] and e["preds"] == [a["preds"][i] for i in keep]
+    assert e["label_logits"] == [a["label_logits"][i] for i in keep]
+    # with the offline sub-word stand-in tokenizer ids must be the same function of the text in every process:
+    # world 2 (each rank's tokenizer warmed on different text) == the single-process run, decoded text and label logits alike
+    s1 = _run_dp(script, tmp_path / "s1", 1, 0, {"DP_STANDIN": "1"})
+    s2 = _run_dp(script, tmp_path / "s2", 2, 29619, {"DP_STANDIN": "1"})
+    assert s1["n"] == s2["n"] == 10 and s1["preds"] == s2["preds"] and s1["preds"][0].startswith("neutral")
+    assert s1["label_logits"] == s2["label_logits"] and s1["label_logits"][0]
 
 
 def test_row_packer_roundtrip_and_result_gather_layout():
