@@ -10,7 +10,10 @@ Differences, all additive:
     ``SyntheticICLDataset`` (same item schema and prompt templates, 30 s clips);
   * data-parallel inference: launched under ``torchrun`` (one process per GPU) the utterances are sharded
     ``i ≡ rank (mod world)`` and rank 0 gathers every rank's results before scoring (the reference's inference is
-    single-process); ``--batch_size`` defaults to 16 because ragged prompts batch fine on this path.
+    single-process); ``--batch_size`` defaults to 64, not the reference's 1 (its collate stacks un-padded prompts, :448-450): ragged prompts
+    batch fine here and a row's results do not depend on its batch (tested bit for bit), so the default is a throughput choice
+    — 64 utterances keep the workspace under ~45 GiB for every supported model; ``--batch_size 256`` is the headline setting
+    (140 utterances/s on one MI355X, ~140 GiB of HBM), ``--batch_size 1`` reproduces the reference's loop shape at ~14/s.
 """
 from __future__ import annotations
 
@@ -57,7 +60,8 @@ def parse_args(argv=None):
     p.add_argument("--input_mode", type=str, default="speech_only", choices=["speech_only", "text_only", "speech_and_text"])
     p.add_argument("--fewshot_mode", type=str, default="text", choices=["text", "speech"])
     p.add_argument("--model_type", type=str, default="salmonn")
-    p.add_argument("--batch_size", type=int, default=16)
+    p.add_argument("--batch_size", type=int, default=64,
+                   help="utterances per generate call (reference default 1; results are batch-invariant; 256 = headline throughput)")
     p.add_argument("--num_examples", type=int, default=5)
     p.add_argument("--num_workers", type=int, default=4)
     p.add_argument("--seed", type=int, default=42)

@@ -241,6 +241,13 @@ class CustomQwen(BaseModel):
         self.batch_counter += 1
         return {"loss": loss, "logits": logits, "labels": labels.to(logits.device)}
 
+    def print_trainable_parameters(self):
+        """Reference :104-116: one log line with the count of parameters that require gradients (none on this inference path:
+        the tree holds frozen parameters) against all parameters."""
+        total = sum(p.numel() for p in self.parameters())
+        trainable = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        logging.info(f"Trainable params: {trainable} ({100 * trainable / max(total, 1):.2f}% of all params)")
+
     def generate_ids(self, batch: Dict[str, Any], want_first_logits: bool = False):
         """Batch dict -> ``GenerateResult`` (new token ids, first-step logits on request); see CustomSALMONN.generate_ids."""
         rows, segs, speech, _, _ = self._rows_and_audio(batch)

@@ -11,7 +11,7 @@ from __future__ import annotations
 import logging
 import time
 import traceback
-from typing import Any, Dict, Optional
+from typing import Any, Dict, List, Optional
 
 import torch
 
@@ -68,19 +68,76 @@ class ModelFactory:
             raise RuntimeError(f"Failed to create model from config: {e}") from e
 
     @staticmethod
-    def optimize_for_inference(model, **_):
-        """Reference: ``.eval()`` + optional ``torch.compile`` (:224-269).  The HIP path has nothing to trace:
-        its kernels are already compiled and the decode loop is captured in a HIP graph by the runtime."""
-        model.eval()
-        return model
+    def clear_cache():
+        """Reference :202-222: empties the (never populated) model cache and the allocator's cache; returns the number of
+        models dropped.  This factory keeps no cache either: what is handed back is the HIP allocator's free blocks."""
+        import gc
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        logger.info("Model cache cleared: 0 models")
+        return 0
 
     @staticmethod
-    def get_model_from_checkpoint(checkpoint_path: str, model_type: str, device=None, **model_kwargs):
-        """Reference: :327-386 — build, ``torch.load``, then the 4-way key dispatch of inference/inference.py:157-177."""
-        model = ModelFactory.create_model(model_type, device=device, **model_kwargs)
-        ckpt = torch.load(checkpoint_path, map_location="cpu")
-        load_finetuned_checkpoint(model, ckpt)
+    def optimize_for_inference(model, device=None):
+        """Reference :224-269: move to ``device``, ``.eval()``, optional ``torch.compile``; the model comes back whatever
+        happens.  The HIP path has nothing to trace: its kernels are compiled ahead of time and the decode loop is captured
+        in a HIP graph by the runtime."""
+        try:
+            if device is not None:
+                model = model.to(device)
+            model.eval()
+        except Exception as e:
+            logger.error("Error optimizing model for inference: %s", e)
         return model
+
+    _MODEL_INFO = {
+        "salmonn": ("SALMONN", "Speech Audio Language Music Open Neural Network", "Multimodal model for speech, audio, and text",
+                    {"llama_path": "/path/to/llama", "whisper_path": "openai/whisper-large-v2", "beats_path": "microsoft/beats"}),
+        "qwen2": ("Qwen2", "Qwen2 Audio", "Multimodal model for audio and text", {"model_path": "Qwen/Qwen2-Audio-7B-Instruct"}),
+    }
+
+    @staticmethod
+    def get_model_info(model_type: str) -> Dict[str, Any]:
+        """Reference :271-315: a description record per model type; unknown type -> ValueError."""
+        try:
+            name, full, desc, paths = ModelFactory._MODEL_INFO[model_type.lower()]
+        except KeyError:
+            raise ValueError(f"Unknown model type: {model_type.lower()}") from None
+        return {"name": name, "full_name": full, "description": desc, "default_paths": dict(paths), "supports_lora": True,
+                "supports_speech": True, "supports_audio": True}
+
+    @staticmethod
+    def get_available_models() -> List[str]:
+        return list(ModelFactory._MODEL_INFO)
+
+    @staticmethod
+    def get_model_from_checkpoint(checkpoint_path: str, base_model_path: str, model_type: str, device=None):
+        """Reference :327-386: build the model on ``base_model_path`` (``llama_path`` for SALMONN, ``model_path`` for Qwen2), load
+        the checkpoint's ``"model"`` / ``"model_state_dict"`` / raw state dict with ``strict=False``; a missing file or any
+        failure -> ``RuntimeError("Failed to load model from checkpoint: ...")``."""
+        import os
+        try:
+            if not os.path.exists(checkpoint_path):
+                raise FileNotFoundError(f"Checkpoint not found at {checkpoint_path}")
+            if model_type == "salmonn":
+                from .custom_salmon import CustomSALMONN
+                model = CustomSALMONN(llama_path=base_model_path, device=device)
+            else:
+                from .custom_qwen import CustomQwen
+                model = CustomQwen(model_path=base_model_path, device=device)
+            ckpt = torch.load(checkpoint_path, map_location="cpu")
+            sd = next((ckpt[k] for k in ("model", "model_state_dict") if k in ckpt), ckpt)
+            missing, unexpected = model.load_state_dict(sd, strict=False)
+            if missing:
+                logger.warning("Missing keys when loading checkpoint: %s", list(missing)[:20])
+            if unexpected:
+                logger.warning("Unexpected keys when loading checkpoint: %s", list(unexpected)[:20])
+            return model
+        except Exception as e:
+            logger.error("Error loading model from checkpoint: %s", e)
+            logger.debug(traceback.format_exc())
+            raise RuntimeError(f"Failed to load model from checkpoint: {e}") from e
 
 
 def load_finetuned_checkpoint(model, checkpoint: Dict[str, Any]) -> int:

@@ -683,6 +683,79 @@ def g14_reference_glue_sentencepiece():
         json.dump(cases, f, indent=1)
 
 
+def _signature_table(fn):
+    """[(name, kind, default repr | None)] of a callable's parameters, `self` / `cls` dropped."""
+    import inspect
+    out = []
+    for name, prm in inspect.signature(fn).parameters.items():
+        if name in ("self", "cls"):
+            continue
+        out.append([name, prm.kind.name, None if prm.default is inspect.Parameter.empty else repr(prm.default)])
+    return out
+
+
+def g15_boundary():
+    """The plugin boundary as the reference declares it: inspect.signature of BaseModel's public methods,
+    ModelFactory's static methods, CustomSALMONN / CustomQwen constructors and entry points, and the action table of the
+    CLI's argparse parser (inference/inference.py:41-91).  Imports only: the absent third-party packages (SALMONN, peft) are
+    empty in-memory modules, nothing is constructed or run."""
+    import argparse
+    import inspect
+    for name in ("SALMONN", "SALMONN.models", "SALMONN.models.salmonn_org", "peft"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["SALMONN.models.salmonn_org"].SALMONN = getattr(sys.modules["SALMONN.models.salmonn_org"], "SALMONN", object)
+    for attr in ("LoraConfig", "get_peft_model", "TaskType"):
+        setattr(sys.modules["peft"], attr, getattr(sys.modules["peft"], attr, object))
+    sys.path.insert(0, REF)
+    for m in ("models.custom_salmon", "models.custom_qwen", "models.model_factory", "models.base_model"):
+        sys.modules.pop(m, None)
+    from models.base_model import BaseModel as RefBase
+    from models.custom_salmon import CustomSALMONN as RefSALMONN
+    from models.custom_qwen import CustomQwen as RefQwen
+    from models.model_factory import ModelFactory as RefFactory
+
+    def public_methods(cls, own_only=True):
+        names = [n for n, v in vars(cls).items() if not n.startswith("_") or n == "__init__"] if own_only else dir(cls)
+        out = {}
+        for n in names:
+            fn = inspect.getattr_static(cls, n)
+            kind = "staticmethod" if isinstance(fn, staticmethod) else "classmethod" if isinstance(fn, classmethod) else "method"
+            target = getattr(cls, n)
+            if callable(target):
+                out[n] = {"kind": kind, "abstract": bool(getattr(target, "__isabstractmethod__", False)),
+                          "params": _signature_table(target)}
+        return out
+
+    table = {"BaseModel": public_methods(RefBase), "CustomSALMONN": public_methods(RefSALMONN),
+             "CustomQwen": public_methods(RefQwen), "ModelFactory": public_methods(RefFactory)}
+    # the CLI: capture the parser the reference's parse_args() builds
+    captured = []
+    real_parse = argparse.ArgumentParser.parse_args
+    argparse.ArgumentParser.parse_args = lambda self, *a, **k: captured.append(self) or argparse.Namespace()
+    try:
+        sys.modules.pop("inference.inference", None)
+        import inference.inference as ref_cli
+        ref_cli.parse_args()
+    finally:
+        argparse.ArgumentParser.parse_args = real_parse
+    actions = []
+    for a in captured[0]._actions:
+        if not a.option_strings or a.dest == "help":
+            continue
+        default = a.default
+        if a.dest == "today":
+            default = "<today %Y-%m-%d>"
+        elif a.dest == "device":
+            default = "<cuda if available else cpu>"
+        actions.append({"flags": a.option_strings, "dest": a.dest, "action": type(a).__name__,
+                        "type": getattr(a.type, "__name__", None), "default": default, "required": bool(a.required),
+                        "choices": list(a.choices) if a.choices else None})
+    table["inference_cli"] = actions
+    with open(os.path.join(HERE, "boundary.json"), "w") as f:
+        json.dump(table, f, indent=1)
+    print("boundary.json:", {k: len(v) for k, v in table.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                  # e.g. `make_golden.py g14_reference_glue_sentencepiece`: regenerate one family only
         for name in sys.argv[1:]:
@@ -701,3 +774,4 @@ if __name__ == "__main__":
     g12_qwen_prompts()
     g13_performance_tracker()
     g14_reference_glue_sentencepiece()
+    g15_boundary()

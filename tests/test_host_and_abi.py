@@ -342,6 +342,90 @@ def test_performance_tracker_matches_reference(monkeypatch):
         assert summary == want["summary"] and lines == want["lines"], interval
 
 
+def test_plugin_boundary_matches_the_reference_signatures():
+    """b-1, mechanically: names, parameter order and defaults of BaseModel / ModelFactory / CustomSALMONN / CustomQwen methods and the
+    CLI's flag table against inspect.signature / argparse actions dumped from the imported reference
+    (tests/golden/make_golden.py::g15_boundary -> boundary.json; models/base_model.py:21-58, models/model_factory.py:29-37,
+    inference/inference.py:41-91).  This surface may ADD (extra keyword parameters after the reference's, extra flags); every
+    other difference must be listed in DELIBERATE below with its reason."""
+    import argparse
+    import inspect
+    from icl_speech_text_llm_amd.inference import inference as cli
+    from icl_speech_text_llm_amd.models.base_model import BaseModel
+    from icl_speech_text_llm_amd.models.custom_qwen import CustomQwen
+    from icl_speech_text_llm_amd.models.custom_salmon import CustomSALMONN
+    from icl_speech_text_llm_amd.models.model_factory import ModelFactory
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "boundary.json")))
+    DELIBERATE = {
+        # ragged prompts batch on this path and results are batch-invariant: the default is a throughput choice (CLI docstring)
+        ("cli", "batch_size", "default"): (1, 64),
+        # argparse's type=bool turns ANY non-empty string into True ("--interleave False" is True in the reference); _bool parses
+        # true/false/1/0 and agrees with the reference on every spelling of True
+        ("cli", "randomize_swap", "type"): ("bool", "_bool"), ("cli", "balance_datasets", "type"): ("bool", "_bool"),
+        ("cli", "interleave", "type"): ("bool", "_bool"),
+    }
+    problems = []
+
+    def table(fn):
+        return [[n, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                for n, p in inspect.signature(fn).parameters.items() if n not in ("self", "cls")]
+
+    for cname, cls in (("BaseModel", BaseModel), ("CustomSALMONN", CustomSALMONN), ("CustomQwen", CustomQwen), ("ModelFactory", ModelFactory)):
+        for mname, g in gold[cname].items():
+            if not hasattr(cls, mname):
+                problems.append(f"{cname}.{mname}: missing")
+                continue
+            raw = inspect.getattr_static(cls, mname)
+            kind = "staticmethod" if isinstance(raw, staticmethod) else "classmethod" if isinstance(raw, classmethod) else "method"
+            if kind != g["kind"]:
+                problems.append(f"{cname}.{mname}: {kind} != {g['kind']}")
+            ours = table(getattr(cls, mname))
+            names = [o[0] for o in ours]
+            ref_named = [r for r in g["params"] if not r[1].startswith("VAR_")]
+            for r in g["params"]:
+                if r[1].startswith("VAR_"):
+                    if not any(o[1] == r[1] for o in ours):
+                        problems.append(f"{cname}.{mname}: no {r[1]} parameter")
+                elif r[0] not in names:
+                    problems.append(f"{cname}.{mname}: parameter {r[0]} missing")
+                elif ours[names.index(r[0])][2] != r[2]:
+                    problems.append(f"{cname}.{mname}({r[0]}): default {ours[names.index(r[0])][2]} != {r[2]}")
+            if [n for n in names if n in {r[0] for r in ref_named}] != [r[0] for r in ref_named]:
+                problems.append(f"{cname}.{mname}: parameter order differs")
+            # positional compatibility: the reference's named parameters come first, in its order
+            if names[:len(ref_named)] != [r[0] for r in ref_named] and [r[0] for r in ref_named] and not problems:
+                problems.append(f"{cname}.{mname}: extra parameters precede the reference's")
+    captured = []
+    real = argparse.ArgumentParser.parse_args
+    argparse.ArgumentParser.parse_args = lambda self, *a, **k: captured.append(self) or argparse.Namespace()
+    try:
+        cli.parse_args([])
+    finally:
+        argparse.ArgumentParser.parse_args = real
+    acts = {a.dest: a for a in captured[0]._actions}
+    for g in gold["inference_cli"]:
+        a = acts.get(g["dest"])
+        if a is None:
+            problems.append(f"cli: flag {g['flags']} missing")
+            continue
+        mine = {"flags": list(a.option_strings), "action": type(a).__name__, "type": getattr(a.type, "__name__", None),
+                "default": g["default"] if g["dest"] in ("today", "device") else a.default, "required": bool(a.required),
+                "choices": list(a.choices) if a.choices else None}
+        for field, val in mine.items():
+            if val != g[field] and DELIBERATE.get(("cli", g["dest"], field)) != (g[field], val):
+                problems.append(f"cli --{g['dest']}: {field} {val!r} != {g[field]!r}")
+    assert not problems, "\n".join(problems)
+    from icl_speech_text_llm_amd.inference.inference import _bool
+    assert _bool("True") is True and _bool("true") is True and _bool("1") is True and _bool("False") is False
+    assert ModelFactory.get_available_models() == ["salmonn", "qwen2"] and ModelFactory.clear_cache() == 0
+    assert set(ModelFactory.get_model_info("SALMONN")) == {"name", "full_name", "description", "default_paths", "supports_lora",
+                                                           "supports_speech", "supports_audio"}
+    with pytest.raises(ValueError):
+        ModelFactory.get_model_info("whisper")
+    with pytest.raises(RuntimeError, match="Failed to load model from checkpoint"):
+        ModelFactory.get_model_from_checkpoint("/nonexistent/ckpt.pth", "", "salmonn")
+
+
 def test_workspace_capacity_is_bounded_and_tracks_generation():
     """buffers are keyed by name with a capacity — 200 distinct ragged row counts keep ONE allocation per
     name (bytes bounded by the largest request), growth bumps `generation` (captured graphs must be retired), and zero=True
