@@ -96,12 +96,12 @@ def parse():
     ap.add_argument("--no-phases", action="store_true", help="skip the extra untimed per-phase step (profiling passes: fewer dispatches)")
     ap.add_argument("--tiny", action="store_true", help="miniature model (smoke only; not a valid bench number)")
     ap.add_argument("--through-plugin", action="store_true",
-                    help="(default at N=1 on the headline workload) also time the path through the reference-compatible plugin: "
+                    help="(default on the headline workload, at every N: with N > 1 each rank runs it on its own shard) also time the path through the reference-compatible plugin: "
                          "ModelFactory -> SalmonProcessor / DataLoader -> generate_output (H2D, tokenisation, batch_decode inside "
                          "the timed region; SURVEY.md §8d)")
     ap.add_argument("--no-through-plugin", action="store_true", help="skip the plugin-path leg")
     ap.add_argument("--plugin-workers", type=int, default=8)
-    ap.add_argument("--plugin-batch", type=int, default=256, help="batch size of the plugin-path leg (same micro-batch as the runtime number)")
+    ap.add_argument("--plugin-batch", type=int, default=None, help="batch size of the plugin-path leg (default: --batch, the micro-batch of the runtime number)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c2s", "c4", "c5"],
                     help="BASELINE.md §4: c2 = headline (default); c2s = 5 speech exemplars; c4 = Qwen2-Audio HVB; "
                          "c5 = Llama2-13B VOXCELEB+HVB+VOXPOPULI round-robin")
@@ -370,78 +370,162 @@ def cpu_baseline_full(sd, cfg, wavs, idss, threads_all: int):
 # ======================================================================================================================
 # the plugin-path number ("dataloader/log-mel included")
 # ======================================================================================================================
-def through_plugin(args, dev, n_batches: int = 5, warm: int = 2):
-    """ModelFactory.create_model -> SalmonProcessor -> DataLoader(num_workers) -> model.generate_output, timed the way the
-    reference's loop counts examples (inference/inference.py:259-266,301-368; utils/performance_utils.py:96-122): H2D of the
-    raw waveforms, the host prompt split + tokenisation, K1..K11 and batch_decode are all inside the timed region.  Also
-    reports the host-only ceiling (items/s one rank's DataLoader can produce) — at 8 ranks the hosts must feed ~8x the
-    per-GPU rate, which decides the >=6x target, not xGMI."""
-    from torch.utils.data import DataLoader
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if xs else None
+
+
+def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batches: int = 5, warm: int = 2, make_model=None,
+                   workers=None):
+    """ModelFactory.create_model -> SalmonProcessor -> DataLoader(num_workers) -> model.generate_ids / decode_ids, timed the way
+    the reference's loop counts examples (inference/inference.py:259-266,301-368; utils/performance_utils.py:96-122): H2D of the
+    raw waveforms, the host prompt split + tokenisation, K1..K11 and batch_decode are all inside the timed region.
+
+    ``world > 1``: EVERY rank runs this leg on its own shard (dataset index i = rank mod world) with its own DataLoader
+    workers, and every batch ends with the ONE fixed-shape all_gather_into_tensor of (index, ids, length, bf16 first-step
+    logits) — the whole per-rank host pipeline whose feed rate decides the 8-GPU scaling (8 ranks x ~140 utt/s x
+    1.9 MB of audio), bracketed by barriers, MAX over ranks.  Rank 0 returns the whole-node rate plus each rank's
+    generate / between-batches times and host-only DataLoader ceiling; the other ranks return None."""
+    from torch.utils.data import DataLoader, Subset
     from icl_speech_text_llm_amd.data.model_processors import get_processor
     from icl_speech_text_llm_amd.data.synthetic_dataset import SyntheticICLDataset
     from icl_speech_text_llm_amd.data.task_configs import DatasetType
     from icl_speech_text_llm_amd.models.model_factory import ModelFactory
+    from icl_speech_text_llm_amd.runtime import dp
+    from icl_speech_text_llm_amd.utils.data_utils import device_prefetch
     from icl_speech_text_llm_amd.utils.performance_utils import PerformanceTracker
-    bs = args.plugin_batch
-    model = ModelFactory.create_model("salmonn", device=str(dev), arch="tiny" if args.tiny else "7b", low_resource=True,
-                                      llama_path="stand-in:subword", ckpt_path="", lora_alpha=32).eval()
+    dev = torch.device(dev)
+    on_gpu = dev.type == "cuda"
+    bs = args.plugin_batch or args.batch
+    workers = args.plugin_workers if workers is None else workers
+    if make_model is None:
+        model = ModelFactory.create_model("salmonn", device=str(dev), arch="tiny" if args.tiny else "7b", low_resource=True,
+                                          llama_path="stand-in:subword", ckpt_path="", lora_alpha=32).eval()
+    else:
+        model = make_model()
     proc = get_processor("salmonn", model.input_processor, model.llama_tokenizer)
     # one batch more than is consumed: the loop below stops before the loader is exhausted, so that tearing the DataLoader's
     # workers down (~0.3 s, once per epoch) does not land between two timed batches of a five-batch measurement
-    ds = SyntheticICLDataset(proc, [DatasetType.VOXCELEB], n_items=bs * (n_batches + warm + 1), num_examples=5,
-                             input_mode="speech_only", fewshot_mode="text", audio_seconds=30.0)
+    per_rank = bs * (n_batches + warm + 1)
+    ds = SyntheticICLDataset(proc, [DatasetType.VOXCELEB], n_items=per_rank * world, num_examples=5,
+                             input_mode="speech_only", fewshot_mode="text", audio_seconds=getattr(args, "plugin_audio_seconds", 30.0))
+    shard = dp.shard_indices(len(ds), rank, world)
 
     def loader():
-        return DataLoader(ds, batch_size=bs, shuffle=False, num_workers=args.plugin_workers, pin_memory=True,
-                          collate_fn=proc.collate_batch, persistent_workers=False)
-    # host ceiling: the DataLoader alone (item synthesis stands in for disk reads + resampling of the real datasets)
+        return DataLoader(Subset(ds, shard) if world > 1 else ds, batch_size=bs, shuffle=False, num_workers=workers,
+                          pin_memory=on_gpu, collate_fn=proc.collate_batch, persistent_workers=False)
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        sync()
+    # host ceiling: this rank's DataLoader alone (item synthesis stands in for disk reads + resampling of the real datasets);
+    # all ranks at once, as in the timed loop: the host cores are shared
+    barrier()
     t0, n_host = time.perf_counter(), 0
     for b_i, batch in enumerate(loader()):
         n_host += len(batch["prompt"])
         if b_i + 1 >= max(2, n_batches // 2):
             break
     host_rate = n_host / (time.perf_counter() - t0)
-    tracker, done, t_start, prompt_tokens, stages, gaps, t_prev_end = None, 0, None, [], [], [], None
+    vocab = len(model.llama_tokenizer)
+    if world > 1:
+        packer = dp.result_packer(NEW_TOKENS, vocab)
+        cdev = dp.collective_device(dist, dev)
+        row_local = packer.alloc(bs, cdev)
+        row_all = torch.empty(world * bs, packer.row_bytes, dtype=torch.uint8, device=cdev)
+    tracker, done, prompt_tokens, stages, gaps, t_prev_end, t_start, t_end = None, 0, [], [], [], None, None, None
+    pad_id, eos_id = model.llama_tokenizer.pad_token_id, model.llama_tokenizer.eos_token_id
     with torch.no_grad():
-        from icl_speech_text_llm_amd.utils.data_utils import device_prefetch
         for b_i, batch in enumerate(device_prefetch(loader(), dev)):      # as the CLI does: batch i+1's H2D under batch i's kernels
             if b_i == warm:
-                torch.cuda.synchronize()
-                tracker, t_start = PerformanceTracker(log_interval=10 ** 9), time.perf_counter()
+                barrier()
+                tracker, t_start, t_prev_end = PerformanceTracker(log_interval=10 ** 9), time.perf_counter(), None
             batch["max_new_tokens"] = NEW_TOKENS
             t1 = time.perf_counter()
             if t_prev_end is not None and tracker is not None:
                 gaps.append(round((t1 - t_prev_end) * 1e3, 1))
-            out = model.generate_output(batch)
+            n_b = len(batch["prompt"])
+            if world > 1:      # the data-parallel CLI's per-batch work: ids + logits as tensors, rank-local decode, one gather
+                res = model.generate_ids(batch, want_first_logits=True)
+                out = model.decode_ids(res.tokens)
+                ids = torch.full((n_b, NEW_TOKENS), pad_id, dtype=torch.int32)
+                ids[:, :res.tokens.shape[1]] = res.tokens.to(torch.int32)
+                is_eos = res.tokens == eos_id
+                glen = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((n_b,), res.tokens.shape[1])).to(torch.int32)
+                idx = torch.tensor(shard[b_i * bs: b_i * bs + n_b], dtype=torch.int64)
+                packer.pack(row_local, index=idx, gen_ids=ids, gen_len=glen, first_logits=res.first_logits)
+                dp.all_gather_rows(dist, row_local, out=row_all)
+            else:
+                out = model.generate_output(batch)
             t_prev_end = time.perf_counter()
             if tracker is not None:
-                tracker.update(time.perf_counter() - t1, len(batch["input_ids"]))
+                tracker.update(t_prev_end - t1, n_b)
                 done += len(out)
-                st = dict(getattr(model, "last_stage_seconds", {}), total=time.perf_counter() - t1)
+                st = dict(getattr(model, "last_stage_seconds", {}), total=t_prev_end - t1)
                 stages.append({k: round(v * 1e3, 1) for k, v in st.items()})
             if b_i == 0:
                 prompt_tokens = [len(model.llama_tokenizer(p, add_special_tokens=False)["input_ids"]) for p in batch["prompt"][:4]]
             if b_i + 1 >= warm + n_batches:
-                torch.cuda.synchronize()
+                barrier()
                 t_end = time.perf_counter()        # before the break: leaving the loop finalises the prefetcher and with it the
-                break                              # DataLoader's workers
+                last_b = b_i                       # DataLoader's workers
+                break
     dt = t_end - t_start
     summ = tracker.get_summary()
+    mine = {"rank": rank, "utterances": done, "seconds": round(dt, 3),
+            "generate_output_ms": [st["total"] for st in stages], "between_batches_ms": gaps,
+            "host_ceiling_utt_per_s": round(host_rate, 1), "host_stage_ms_last_batch": stages[-1] if stages else None,
+            "examples_per_second_tracker": summ.get("examples_per_second")}
+    note = ("ModelFactory -> SalmonProcessor/DataLoader -> generate_output; H2D of raw audio, prompt split + tokenisation "
+            "(stand-in sub-word tokenizer at ~3.9 chars per token: no Llama tokenizer files offline; prompt positions as listed, vs the "
+            "frozen 376), K1..K11 and batch_decode inside the timed region; first batches excluded as warm-up; utt_per_s counts every "
+            "timed batch (a batch whose ragged prompt lengths open a new decode-graph key pays its capture), utt_per_s_steady is "
+            "the median batch")
+    if world == 1:
+        del model
+        if on_gpu:
+            torch.cuda.empty_cache()
+        return {"utt_per_s": round(done / dt, 2), "examples_per_second_tracker": summ.get("examples_per_second"),
+                "batch_size": bs, "batches_timed": n_batches, "dataloader_workers": workers,
+                "host_ceiling_utt_per_s_per_rank": round(host_rate, 1),
+                "host_stage_ms_last_batch": stages[-1] if stages else None,
+                "generate_output_ms_per_batch": mine["generate_output_ms"], "between_batches_ms": gaps,
+                "utt_per_s_steady": (round(bs / (_median(mine["generate_output_ms"]) * 1e-3), 2) if stages else None),
+                "prompt_positions_first_rows": [t + N_AUDIO_TOK for t in prompt_tokens], "note": note}
+    # ---- world > 1: MAX over ranks, every rank's figures to rank 0 (objects, outside the timed region) ----------------------
+    tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    ok_idx = None
+    if rank == 0:
+        got = packer.unpack(row_all)
+        want = sorted(i for r in range(world) for i in dp.shard_indices(len(ds), r, world)[last_b * bs:(last_b + 1) * bs])
+        ok_idx = sorted(got["index"].cpu().tolist()) == want
     del model
-    torch.cuda.empty_cache()
-    return {"utt_per_s": round(done / dt, 2), "examples_per_second_tracker": summ.get("examples_per_second"),
-            "batch_size": bs, "batches_timed": n_batches, "dataloader_workers": args.plugin_workers,
-            "host_ceiling_utt_per_s_per_rank": round(host_rate, 1),
-            "host_stage_ms_last_batch": stages[-1] if stages else None,
-            "generate_output_ms_per_batch": [st["total"] for st in stages],
-            "between_batches_ms": gaps,
-            "utt_per_s_steady": (round(bs / (sorted(st["total"] for st in stages)[len(stages) // 2] * 1e-3), 2) if stages else None),
-            "prompt_positions_first_rows": [t + N_AUDIO_TOK for t in prompt_tokens],
-            "note": "ModelFactory -> SalmonProcessor/DataLoader -> generate_output; H2D of raw audio, prompt split + tokenisation "
-                    "(stand-in sub-word tokenizer at ~3.9 chars per token: no Llama tokenizer files offline; prompt positions as listed, vs the "
-                    "frozen 376), K1..K11 and batch_decode inside the timed region; first batches excluded as warm-up; utt_per_s counts every "
-                    "timed batch (a batch whose ragged prompt lengths open a new decode-graph key pays its capture), utt_per_s_steady is "
-                    "the median batch"}
+    if on_gpu:
+        torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    gen = [x for m in everyone for x in m["generate_output_ms"]]
+    gap = [x for m in everyone for x in m["between_batches_ms"]]
+    return {"utt_per_s": round(sum(m["utterances"] for m in everyone) / float(tt.item()), 2), "n_ranks": world,
+            "batch_size_per_rank": bs, "batches_timed_per_rank": n_batches, "seconds_max_over_ranks": round(float(tt.item()), 3),
+            "collective": f"all_gather_into_tensor per batch, {bs * packer.row_bytes} B per rank ({dist.get_backend()})",
+            "last_batch_indices_ok": ok_idx,
+            "generate_output_ms": {"min": min(gen), "median": _median(gen), "max": max(gen)},
+            "between_batches_ms": {"min": min(gap), "median": _median(gap), "max": max(gap)} if gap else None,
+            "host_ceiling_utt_per_s_per_rank": {"min": min(m["host_ceiling_utt_per_s"] for m in everyone),
+                                                "max": max(m["host_ceiling_utt_per_s"] for m in everyone)},
+            "host_cores": host_cores(), "host_threads_per_rank": torch.get_num_threads(), "dataloader_workers_per_rank": workers,
+            "per_rank": everyone, "prompt_positions_first_rows": [t + N_AUDIO_TOK for t in prompt_tokens],
+            "note": note + "; world > 1: every rank runs its own DataLoader workers on its own shard (i = rank mod world), "
+                           "times are bracketed by barriers, utt_per_s = all ranks' utterances / MAX over ranks of the wall time"}
 
 
 def main():
@@ -452,6 +536,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1) and rank == 0:
         log(f"note: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus reports {world}")
+    # host threads and DataLoader workers per rank are bounded BEFORE anything touches the GPU: 8 ranks share the node's cores
+    cores = host_cores()
+    cores_per_rank = max(1, cores // max(world, 1))
+    if world > 1:
+        torch.set_num_threads(cores_per_rank)
+    plugin_workers = args.plugin_workers if world == 1 else max(1, min(args.plugin_workers, cores_per_rank - 1))
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
@@ -657,6 +747,20 @@ def main():
         }
         log(f"phases: encoder {t_enc * 1e3:.1f} ms, prefill {t_pre * 1e3:.1f} ms, decode {t_dec * 1e3:.1f} ms")
     parity_failed = False
+    want_plugin = args.workload == "c2" and not args.no_through_plugin and (args.through_plugin or not args.tiny)
+    plugin_block = None
+    if world > 1 and want_plugin:
+        # every rank: hand the runtime leg's model and workspace back first (the plugin builds its own replica), then the
+        # whole per-rank host pipeline + the per-batch gather, barriers on both sides
+        hbm_peak = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)
+        ws_gib = round(rt.ws.nbytes() / 2 ** 30, 2)
+        del rt
+        torch.cuda.empty_cache()
+        log(f"through-plugin leg on all {world} ranks ({plugin_workers} DataLoader workers, {cores_per_rank} host threads per rank) ...")
+        # no try / except here: a rank that fails must take the job down (non-zero exit under the launcher), not leave the
+        # others waiting in a collective
+        plugin_block = through_plugin(args, dev, dist=dist, rank=rank, world=world, workers=plugin_workers)
+        rt = None
     if rank == 0:
         n_utt = Bm * args.steps * world
         out = {
@@ -671,20 +775,25 @@ def main():
                        "audio_seconds": 30, "new_tokens": NEW_TOKENS, "parallelism": f"dp{world}",
                        "weights": "seeded N(0,0.02^2) bf16, LoRA r=8 un-merged"},
             "roofline": roof, "phases": phases, "gather": gather_info,
-            "workspace_gib": round(rt.ws.nbytes() / 2 ** 30, 2),
+            "workspace_gib": round(rt.ws.nbytes() / 2 ** 30, 2) if rt is not None else ws_gib,
             "build_s": round(t_build, 1), "first_utterance_tokens": first_tokens,
+            "host": {"cores": cores, "ranks": world, "threads_per_rank": torch.get_num_threads(),
+                     "dataloader_workers_per_rank": plugin_workers},
         }
-        out["hbm_peak_gib_timed_loop"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)
+        out["hbm_peak_gib_timed_loop"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1) if rt is not None else hbm_peak
+        if plugin_block is not None:
+            out["through_plugin"] = plugin_block
+            log(f"through-plugin (all ranks): {json.dumps({k: v for k, v in plugin_block.items() if k not in ('per_rank', 'note')})}")
         if world == 1:
             # the side legs below build a second model (plugin) and a third set of decoder weights (margin parity) next to this
             # one: hand the 94 GiB of micro-batch-256 workspace back first (the parity legs run one utterance and re-grow
             # what they need)
             rt.ws.clear()
             torch.cuda.empty_cache()
-        if world == 1 and args.workload == "c2" and not args.no_through_plugin and (args.through_plugin or not args.tiny):
+        if world == 1 and want_plugin:
             log("through-plugin leg ...")
             try:
-                out["through_plugin"] = through_plugin(args, dev)
+                out["through_plugin"] = through_plugin(args, dev, workers=plugin_workers)
             except Exception as e:       # a reported side number must never cost the headline line
                 out["through_plugin"] = {"error": f"{type(e).__name__}: {e}"}
             log(f"through-plugin: {out['through_plugin']}")

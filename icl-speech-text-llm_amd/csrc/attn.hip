@@ -510,16 +510,17 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
 // both blocks, exactly as above; the scalar (non-packed) score math keeps the shadow usable.  Arithmetic per query is that of
 // the generic kernel operation for operation (k-step order per accumulator, softmax formulas, sequential row sum).
 // (the causal form is not on any model's path here: it gets the registers it asks for instead of spilling at two waves per SIMD)
-#ifndef IL64_NW
-#define IL64_NW 4      // waves per workgroup of the interleaved kernel (64 queries each).  8 (512 queries share a staged K / V tile,
-                       // half the LDS-DMA instructions per wave) is bit-identical and measured 2-3.5 % SLOWER on both encoder shapes
-#endif
+constexpr int IL64_NW = 4;   // waves per workgroup of the interleaved kernel (64 queries each).  An 8-wave form (512 queries share a
+                             // staged K / V tile, half the LDS-DMA instructions per wave) was bit-identical and 2-3.5 % SLOWER on both
+                             // encoder shapes (profiles/r02_attn_ablations.log); it is gone: one instantiation, its invariants asserted
 template <bool CAUSAL, int NW>
 __global__ __launch_bounds__(64 * NW, CAUSAL ? 1 : 2) void attn_fwd_il64_kernel(AttnParams p) {
   constexpr int D = 64, QB = 2, BQ = 32 * NW * QB, ROWB = D * 2, KS = D / 16, DB = D / 32, CPR = D / 8;
   constexpr int NCH = 64 * CPR / (64 * NW), RPI = 64 / CPR, BUF = 2 * 64 * ROWB, NBUF = 3;
   constexpr int EPI = NW * QB * 32 * (D * 2 + 16);       // the epilogue's per-wave transposition buffers reuse the ring
-  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF > EPI ? NBUF * BUF : EPI];
+  static_assert(NW == 4 && NCH == 2, "the counted waits below (vmcnt(4) = one tile of 2 K + 2 V LDS-DMA per wave in flight) are for 4 waves");
+  static_assert(EPI <= NBUF * BUF, "the epilogue staging must fit inside the K / V ring it reuses");
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hh = lane >> 5;
@@ -672,8 +673,7 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 1 : 2) void attn_fwd_il64_kernel(
 
   stage_tile(0, 0);
   stage_tile(min(1, n_tiles - 1), 1);
-  if constexpr (NCH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // tile 0 (this wave's 4 oldest LDS-DMA) has landed, tile 1 stays in flight
   __syncthreads();
   int cur = 0;
 
@@ -759,8 +759,7 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 1 : 2) void attn_fwd_il64_kernel(
 #pragma unroll
         for (int d = 0; d < DB; ++d)
           o_acc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb][s][d], pf1[kb][s], o_acc[1][d], 0, 0, 0);
-    if constexpr (NCH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's share of tile t+1 has landed; t+2 stays in flight
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's share of tile t+1 has landed; t+2 stays in flight
     __builtin_amdgcn_s_barrier();
     cur = cur + 1 == NBUF ? 0 : cur + 1;
   };

@@ -205,6 +205,7 @@ def run_inference(args) -> Dict[str, Any]:
         rows: Dict[int, Dict[str, Any]] = {}         # dataset index -> record (strings) of THIS rank
         ids_l, len_l, logit_l, idx_l = [], [], [], []
         failed_batches = failed_rows = 0
+        fatal = None
         with torch.no_grad():
             for batch_idx, batch in enumerate(device_prefetch(loader, args.device)):      # batch i+1's H2D under batch i's kernels
                 n_b = len(batch["prompt"])
@@ -235,13 +236,25 @@ def run_inference(args) -> Dict[str, Any]:
                                           "predicted_label (cleaned)": clean_prediction(out, dt_i),
                                           "predicted_label": out.strip(), "dataset_type": DatasetType(dt_i).value}
                     tracker.update(dt, len(keep))
-                except (torch.cuda.OutOfMemoryError, IclError):
-                    raise        # device-side failures are not "a bad sample": stop with a non-zero exit code
+                except (torch.cuda.OutOfMemoryError, IclError) as e:
+                    # device-side failures are not "a bad sample": stop with a non-zero exit code — on EVERY rank (the others
+                    # would otherwise wait in the result gather until the collective times out): leave the loop here, exchange
+                    # the flag below, raise everywhere
+                    fatal = e
+                    logger.error("Device-side failure in batch %d (dataset indices %s): %s", batch_idx, b_idx, e)
+                    break
                 except Exception as e:   # a failed batch is logged and skipped, as in the reference (:370-373)
                     failed_batches += 1
                     logger.error("Error processing batch %d (dataset indices %s): %s", batch_idx, b_idx, e)
                     logger.debug(traceback.format_exc())
                     continue
+        if world > 1:
+            flag = torch.tensor([1.0 if fatal is not None else 0.0], device=collective_device(dist, args.device))
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if fatal is None and flag.item() > 0:
+                fatal = RuntimeError("a device-side failure on another rank (see its log)")
+        if fatal is not None:
+            raise fatal
         perf = tracker.get_summary()
         perf["failed_batches"], perf["failed_rows"] = failed_batches, failed_rows
         if world > 1:

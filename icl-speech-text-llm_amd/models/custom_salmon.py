@@ -140,8 +140,16 @@ class PackedTreeModule(nn.Module):
 
     offload_tree = True
 
+    @staticmethod
+    def _indexed(device) -> torch.device:
+        """``cuda`` -> ``cuda:<current>``: device comparisons below must not see "cuda" and "cuda:0" as different places."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        return device
+
     def _init_tree(self, device, tensors):
-        self._device = torch.device(device)
+        self._device = self._indexed(device)
         _build_tree(self, tensors)
         self._runtime = None
 
@@ -149,15 +157,24 @@ class PackedTreeModule(nn.Module):
         raise NotImplementedError
 
     def _apply(self, fn, *a, **kw):
-        probe = fn(torch.empty(0, device=self._device))
-        if self._runtime is not None and probe.device == self._device:
+        probe = fn(torch.empty(0, dtype=torch.bfloat16, device=self._device))
+        target = self._indexed(probe.device)
+        if probe.dtype != torch.bfloat16:
+            # .half() / .float() / .to(dtype): the packed runtime computes in bf16 with f32 accumulation whatever the tree holds
+            # (the north-star precision); say so instead of silently ignoring the request
+            logger.warning("%s: dtype change to %s ignored — the HIP path keeps bf16 weights and f32 accumulation",
+                           type(self).__name__, probe.dtype)
+            if target == self._device:
+                return self
+            fn = lambda t: t.to(target)          # noqa: E731  (keep the move, drop the cast)
+        if self._runtime is not None and target == self._device:
             return self                          # nothing to move: the runtime already lives there
-        if probe.device.type == "cuda" and any(p.device.type == "cpu" for p in self.parameters()):
-            self._device, self._runtime = probe.device, None      # host-resident tree: packed straight to the new device
+        if target.type == "cuda" and any(p.device.type == "cpu" for p in self.parameters()):
+            self._device, self._runtime = target, None      # host-resident tree: packed straight to the new device
             return self
         out = super()._apply(fn, *a, **kw)
         self._runtime = None
-        self._device = probe.device
+        self._device = target
         return out
 
     @property

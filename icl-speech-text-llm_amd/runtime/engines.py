@@ -25,10 +25,12 @@ class Workspace:
     on almost every call) therefore reuse the same storage — resident bytes are bounded by the largest batch, not by
     the number of distinct shapes — and the steady-state loop performs no allocation.
 
-    ``generation`` counts reallocations: anything that baked raw pointers (captured decode graphs) must be dropped when
-    it moves (``CausalLMRuntimeMixin`` does).  ``zero=True`` buffers carry regions the kernels never write and rely on being
+    ``generation`` counts reallocations of the buffers a captured decode graph points into (``GRAPH_VISIBLE`` name prefixes):
+    anything that baked raw pointers must be dropped when they move (``CausalLMRuntimeMixin`` does).  ``zero=True`` buffers carry regions the kernels never write and rely on being
     zero (conv padding rows, the LoRA augmentation tail): those regions sit at fixed flat offsets for fixed inner
     dimensions, so the buffer is zero-filled when it is (re)allocated and again whenever the inner dimensions change."""
+
+    GRAPH_VISIBLE = ("dc_", "gen_", "kv_")      # buffers a captured decode graph bakes pointers into (decode_step, generate, cache)
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -49,7 +51,9 @@ class Workspace:
             cap = max(n, 1) + (max(n, 1) >> 4)
             if ent is not None:
                 ent[0] = None                   # release the old block before asking for the larger one
-                self.generation += 1
+                if name.startswith(self.GRAPH_VISIBLE):
+                    self.generation += 1        # only a move of something a graph points into retires the graphs: an encoder
+                                                # or prefill buffer growing (a longer clip, a longer prompt) leaves them valid
             flat = (torch.zeros if zero else torch.empty)(cap, dtype=dtype, device=self.device)
             ent = self._bufs[key] = [flat, shape[1:]]
         elif zero and ent[1] != shape[1:]:
@@ -343,12 +347,17 @@ class SpeechQFormerHIP:
 class LlamaHIP:
     decode_packed_weights = True     # micro-batch <= 256: decode GEMMs stream decode-packed copies of the layer weights
 
-    def __init__(self, w: PackedLlama, device):
+    def __init__(self, w: PackedLlama, device, decode_packed: Optional[bool] = None, pack_now: bool = True):
+        """``decode_packed`` (default: the class attribute): keep a second, decode-packed layout of the layer weights (+12.9 GB
+        at 7B, +25 GB at 13B).  ``pack_now=False`` defers the copy to the first decode step — forward-only users
+        (``forward_logits`` / loss) then never pay for it; the default packs at load time, not inside a caller's first batch."""
         self.w = w
         self.device = torch.device(device)
         self.n_cu = max(B.device_cu_count(), 1)
-        if self.decode_packed_weights:
-            self.ensure_decode_packed()          # at load time, not inside a caller's first batch
+        if decode_packed is not None:
+            self.decode_packed_weights = bool(decode_packed)
+        if self.decode_packed_weights and pack_now:
+            self.ensure_decode_packed()
 
     def ensure_decode_packed(self):
         """Decode-packed copies of the layer weights (second layout of the same bytes: +12.9 GB at 7B, +25 GB at 13B)."""

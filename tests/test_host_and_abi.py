@@ -206,6 +206,54 @@ def test_data_parallel_sharding_gloo_world2(tmp_path):
     assert s1["label_logits"] == s2["label_logits"] and s1["label_logits"][0]
 
 
+_BENCH_DP_SCRIPT = r"""
+import argparse, json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import bench
+from icl_speech_text_llm_amd.models.model_factory import ModelFactory
+from icl_speech_text_llm_amd.runtime.salmonn import GenerateResult
+import icl_speech_text_llm_amd.models.custom_salmon as cs
+
+def fake_generate_ids(self, samples, want_first_logits=False):     # CPU stand-in for the HIP generate (DP plumbing only)
+    tok, V = self.llama_tokenizer, len(self.llama_tokenizer)
+    n = len(samples["prompt"])
+    toks = torch.tensor([[3 + (len(p) + t) % 200 for t in range(10)] for p in samples["prompt"]], dtype=torch.int64)
+    first = torch.stack([torch.arange(V, dtype=torch.float32) * 0.5 + len(p) % 11 for p in samples["prompt"]])
+    self.last_stage_seconds = {"speech_launch": 0.0, "segments": 0.0, "generate": 0.0}
+    return GenerateResult(tokens=toks, first_logits=first)
+cs.CustomSALMONN.generate_ids = fake_generate_ids
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+args = argparse.Namespace(plugin_batch=None, batch=3, plugin_workers=0, tiny=True, plugin_audio_seconds=0.5)
+block = bench.through_plugin(args, "cpu", dist=dist, rank=rank, world=world, n_batches=2, warm=1, workers=0,
+                             make_model=lambda: ModelFactory.create_model("salmonn", device="cpu", arch="tiny", ckpt_path="").eval())
+if rank == 0:
+    json.dump(block, open(os.path.join(sys.argv[2], "plugin.json"), "w"))
+else:
+    assert block is None
+dist.destroy_process_group()
+"""
+
+
+def test_bench_through_plugin_leg_runs_on_every_rank_gloo_world2(tmp_path):
+    """at N > 1 bench.py's through-plugin leg (DataLoader -> H2D -> generate -> pack -> ONE all_gather_into_tensor
+    per batch, barriers on both sides) runs on EVERY rank on its own shard, and rank 0 reports the whole-node rate next to each
+    rank's generate / between-batches times and host ceiling.  Two ranks over gloo with a CPU stand-in for the HIP generate."""
+    script = tmp_path / "bench_dp.py"
+    script.write_text(_BENCH_DP_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", str(script), ROOT, str(tmp_path)]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    b = json.load(open(tmp_path / "plugin.json"))
+    assert b["n_ranks"] == 2 and b["batch_size_per_rank"] == 3 and b["batches_timed_per_rank"] == 2
+    assert b["last_batch_indices_ok"] is True and "all_gather_into_tensor" in b["collective"]
+    assert [m["rank"] for m in b["per_rank"]] == [0, 1] and all(m["utterances"] == 6 for m in b["per_rank"])
+    assert all(len(m["generate_output_ms"]) == 2 and len(m["between_batches_ms"]) == 1 for m in b["per_rank"])
+    assert b["utt_per_s"] > 0 and b["generate_output_ms"]["min"] <= b["generate_output_ms"]["max"]
+    assert b["host_ceiling_utt_per_s_per_rank"]["min"] > 0 and b["host_cores"] >= 1 and b["host_threads_per_rank"] >= 1
+
+
 def test_row_packer_roundtrip_and_result_gather_layout():
     """runtime/dp.py byte rows: every field 16-byte aligned, round trip exact for int64 / int32 / bf16 (odd vocabulary width),
     zero-width logits allowed."""
@@ -438,21 +486,28 @@ def test_workspace_capacity_is_bounded_and_tracks_generation():
     rng = np.random.default_rng(0)
     sizes = rng.integers(1, 5000, 200).tolist()
     for m in sizes:
-        t = ws.get("pf_qkv", (m, 96), torch.bfloat16)
+        t = ws.get("dc_qkv", (m, 96), torch.bfloat16)
         assert t.shape == (m, 96) and t.is_contiguous()
-        ws.get("pf_h", (m, 32), torch.float32)
+        ws.get("gen_h", (m, 32), torch.float32)
     assert max(sizes) * (96 * 2 + 32 * 4) <= ws.nbytes() <= int(max(sizes) * (96 * 2 + 32 * 4) * 1.0625) + 8   # 1/16 regrowth headroom
     gen = ws.generation
     assert 0 < gen <= 2 * 12          # ~ln(200) record highs per name, not one per shape
     # the bench's ragged batches: totals that creep up by a fraction of a percent reallocate once, not once per record
     ws2 = Workspace("cpu")
     for m in (47744, 47900, 47950, 48000, 48128, 48100):
-        ws2.get("pf_h", (m, 8), torch.float32)
+        ws2.get("gen_h", (m, 8), torch.float32)
     assert ws2.generation == 0
-    a = ws.get("pf_qkv", (17, 96), torch.bfloat16)
-    b = ws.get("pf_qkv", (4000, 96), torch.bfloat16)
+    a = ws.get("dc_qkv", (17, 96), torch.bfloat16)
+    b = ws.get("dc_qkv", (4000, 96), torch.bfloat16)
     assert a.data_ptr() == b.data_ptr() and ws.generation == gen          # within capacity: same storage, no bump
-    ws.get("pf_qkv", (6000, 96), torch.bfloat16)
+    ws.get("dc_qkv", (6000, 96), torch.bfloat16)
+    assert ws.generation == gen + 1
+    # only buffers a captured decode graph points into (dc_* / gen_* / kv_*) retire the graphs when they move;
+    # an encoder or prefill buffer outgrowing its capacity (a longer clip, a longer prompt) does not
+    ws.get("pf_qkv", (100, 96), torch.bfloat16)
+    ws.get("pf_qkv", (9000, 96), torch.bfloat16)
+    ws.get("wh_ff", (10, 8), torch.bfloat16)
+    ws.get("wh_ff", (1000, 8), torch.bfloat16)
     assert ws.generation == gen + 1
     # zero=True: tail columns stay zero across row counts; a change of inner dims re-zeroes
     z = ws.get("xn", (8, 40), torch.float32, zero=True)
