@@ -183,8 +183,10 @@ class BaseMultiTaskDataset(Dataset):
                 examples.append({"text": ex[cfg.text_key],
                                  "label": self._format_label(ex[cfg.completion_key], is_example=False,
                                                              current_mapping=cfg.label_mapping, text=ex[cfg.text_key])})
-                if self.fewshot_mode == "speech" and ex.get("audio") is not None and _cell_wave(ex["audio"]) is not None:
-                    examples_audio.append(_cell_wave(ex["audio"]))
+                if self.fewshot_mode == "speech" and ex.get("audio") is not None:
+                    wave = _cell_wave(ex["audio"])           # decoded ONCE per exemplar (a 30 s WAV cell is ~1 MB of parsing)
+                    if wave is not None:
+                        examples_audio.append(wave)
         else:
             selected = self._select_examples(item.get("few_shot_examples", []))
             examples = [{"text": ex["text"],

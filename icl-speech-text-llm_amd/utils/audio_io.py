@@ -86,14 +86,27 @@ def decode_audio(cell: Any, target_sr: int = TARGET_SR) -> Optional[np.ndarray]:
     else:
         x = np.asarray(cell, dtype=np.float32)
     if x.ndim == 2:                                  # [n, channels] (WAV) or [channels, n] (decoded multi-channel cell)
+        _note_once("downmix", "multi-channel audio cell mixed down to mono (the reference feeds cells to the model unchanged)")
         x = x.mean(axis=1 if x.shape[1] <= 8 and x.shape[0] > x.shape[1] else 0)
     x = x.reshape(-1)
     if sr != target_sr and x.size:
+        _note_once("resample", f"audio cell at {sr} Hz resampled to {target_sr} Hz (the reference feeds cells to the model unchanged)")
         from math import gcd
         from scipy.signal import resample_poly
         g = gcd(int(sr), int(target_sr))
         x = resample_poly(x.astype(np.float64), target_sr // g, sr // g).astype(np.float32)
     return np.ascontiguousarray(x, dtype=np.float32)
+
+
+_NOTED = set()
+
+
+def _note_once(key: str, msg: str) -> None:
+    """One log line per kind of divergence from the reference's pass-through (not one per cell)."""
+    if key not in _NOTED:
+        _NOTED.add(key)
+        import logging
+        logging.getLogger(__name__).warning(msg)
 
 
 def audio_backend_available() -> bool:
@@ -108,16 +121,49 @@ def audio_backend_available() -> bool:
 
 
 def undecoded_audio_columns(dataset):
-    """Cast ``Audio``-typed columns (top level, or inside a list of dicts such as ``few_shot_examples``) to ``decode=False`` when
-    no decoder backend is importable, so that rows carry ``{"bytes", "path"}`` for ``decode_audio`` instead of raising."""
+    """Cast ``Audio``-typed features — top-level columns AND ``Audio`` leaves nested in dict / list / ``Sequence`` features such
+    as a ``few_shot_examples`` list of dicts — to ``decode=False`` when no decoder backend is importable, so that rows carry
+    ``{"bytes", "path"}`` for ``decode_audio`` instead of raising on access."""
     if audio_backend_available():
         return dataset
     try:
-        from datasets import Audio
+        from datasets import Audio, Features
     except Exception:
         return dataset
+
+    def undecoded(feat):
+        """(rewritten feature, changed?) with every decoding Audio leaf switched to decode=False."""
+        if isinstance(feat, Audio):
+            if getattr(feat, "decode", True):
+                return Audio(sampling_rate=feat.sampling_rate, decode=False), True
+            return feat, False
+        if isinstance(feat, dict):
+            parts = {k: undecoded(v) for k, v in feat.items()}
+            return {k: v[0] for k, v in parts.items()}, any(v[1] for v in parts.values())
+        if isinstance(feat, (list, tuple)) and len(feat) == 1:
+            inner, ch = undecoded(feat[0])
+            return [inner], ch
+        inner_feat = getattr(feat, "feature", None)             # ``List`` / ``LargeList`` / legacy ``Sequence`` containers
+        if inner_feat is not None:
+            inner, ch = undecoded(inner_feat)
+            if not ch:
+                return feat, False
+            import copy
+            out = copy.copy(feat)                               # same container type and length, new element feature
+            out.feature = inner
+            return out, True
+        return feat, False
+
     feats = getattr(dataset, "features", None) or {}
-    for name, feat in list(feats.items()):
-        if isinstance(feat, Audio) and getattr(feat, "decode", True):
-            dataset = dataset.cast_column(name, Audio(sampling_rate=feat.sampling_rate, decode=False))
+    new, changed = {}, False
+    for name, feat in feats.items():
+        new[name], ch = undecoded(feat)
+        changed = changed or ch
+    if changed:
+        try:
+            dataset = dataset.cast(Features(new))
+        except Exception:                                     # fall back to the top-level columns only
+            for name, feat in list(feats.items()):
+                if isinstance(feat, Audio) and getattr(feat, "decode", True):
+                    dataset = dataset.cast_column(name, Audio(sampling_rate=feat.sampling_rate, decode=False))
     return dataset

@@ -559,6 +559,20 @@ def test_audio_cells_decode_without_a_datasets_backend(tmp_path):
         decode_audio({"bytes": b"fLaC" + b"\0" * 64})
     # through an HF dataset folder with an Audio-typed column and the item pipeline
     import datasets
+    # Audio leaves nested in a list-of-dicts column (few_shot_examples) are switched to decode=False as well
+    nested = datasets.Dataset.from_dict(
+        {"few_shot_examples": [[{"text": "a", "audio": {"bytes": pcm16(x[:800]), "path": None}}]],
+         "audio": [{"bytes": pcm16(x), "path": None}]})
+
+    def typed_as(decode):
+        return datasets.Features({"few_shot_examples": [{"text": datasets.Value("string"),
+                                                         "audio": datasets.Audio(sampling_rate=16000, decode=decode)}],
+                                  "audio": datasets.Audio(sampling_rate=16000, decode=decode)})
+    nested = nested.cast(typed_as(False)).cast(typed_as(True))          # what a real folder declares: decoding Audio leaves
+    nested = undecoded_audio_columns(nested)
+    if not audio_backend_available():
+        row = nested[0]                                         # would raise (no decoder) if any Audio leaf still decoded
+        assert decode_audio(row["few_shot_examples"][0]["audio"]).shape == (800,) and decode_audio(row["audio"]).shape == x.shape
     from icl_speech_text_llm_amd.data import task_configs as tc
     from icl_speech_text_llm_amd.data.dataset_factory import DatasetFactory
     from icl_speech_text_llm_amd.data.model_processors import SalmonProcessor
