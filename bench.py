@@ -46,6 +46,8 @@ SPEECH_AT = 280             # the <SpeechHere> slot sits near the end of the VOX
 # Under the frozen N(0, 0.02^2) weights the 32-layer decoder amplifies rounding noise: the oracle's OWN two precisions
 # (bf16 hook vs fp32) differ by 3.3e-2 in the first-step logits, the HIP path sits 2.7e-2 from the bf16 oracle — hence the
 # loose decoder bounds on those weights and the tight one on the well-conditioned margin set.
+PARITY_RATIO = 1.25     # where a pure-fp32 oracle run exists: rel(gpu, fp32) <= PARITY_RATIO * rel(bf16-rounding oracle, fp32) — the
+                        # HIP path may not sit further from the exact arithmetic than the reference's own bf16 rounding points do
 PARITY_BOUNDS = {"logmel": 1e-6, "whisper": 8e-3, "beats": 3e-3, "encode_speech": 6e-3, "prefill_last_hidden": 6e-2,
                  "first_step_logits": 6e-2, "decode_step_logits": 6e-2, "margin_step_logits": 6e-3}
 
@@ -289,6 +291,11 @@ def full_size_parity(cfg, sd_host, rt, dev, wav: np.ndarray, ids: np.ndarray, fp
             stages[name]["bf16_oracle_vs_fp32_oracle_rel_l2"] = _rel(b_, f_)
         stages["first_step_logits"].update(rel_l2_vs_fp32=_rel(step_g[0], fp32_first), max_abs_vs_fp32=_maxabs(step_g[0], fp32_first),
                                            bf16_oracle_vs_fp32_oracle_rel_l2=_rel(tf[0], fp32_first))
+    ratio_ok = True
+    for name, v in stages.items():
+        if "bf16_oracle_vs_fp32_oracle_rel_l2" in v:
+            v["ratio_to_bf16_oracle_distance"] = v["rel_l2_vs_fp32"] / max(v["bf16_oracle_vs_fp32_oracle_rel_l2"], 1e-30)
+            ratio_ok = ratio_ok and v["ratio_to_bf16_oracle_distance"] <= PARITY_RATIO
     rels, errs, margins, within, exact = [], [], [], 0, 0
     for t in range(NEW_TOKENS):
         err = _maxabs(step_g[t], tf[t])
@@ -299,7 +306,7 @@ def full_size_parity(cfg, sd_host, rt, dev, wav: np.ndarray, ids: np.ndarray, fp
     decode = {"rel_l2_max": max(rels), "max_abs_max": max(errs), "oracle_top1_margin_min": min(margins),
               "gpu_choice_is_oracle_argmax_within_2x_logit_error": f"{within}/{NEW_TOKENS}",
               "gpu_choice_equals_oracle_argmax": f"{exact}/{NEW_TOKENS}", "gpu_tokens": toks.tolist()}
-    ok = within == NEW_TOKENS
+    ok = within == NEW_TOKENS and ratio_ok
     for k, b in PARITY_BOUNDS.items():
         if k in stages:
             ok = ok and stages[k]["rel_l2"] <= b
@@ -309,7 +316,9 @@ def full_size_parity(cfg, sd_host, rt, dev, wav: np.ndarray, ids: np.ndarray, fp
             v[k] = float(f"{v[k]:.3e}")
     for k in ("rel_l2_max", "max_abs_max", "oracle_top1_margin_min"):
         decode[k] = float(f"{decode[k]:.3e}")
-    return {"stages": stages, "decode_steps_teacher_forced": decode, "oracle_seconds": round(t_oracle, 1), "ok": bool(ok)}
+    return {"stages": stages, "decode_steps_teacher_forced": decode, "oracle_seconds": round(t_oracle, 1),
+            "ratio_criterion": f"rel(gpu, fp32) <= {PARITY_RATIO} x rel(bf16 oracle, fp32) wherever an fp32 oracle run exists",
+            "ratio_ok": bool(ratio_ok), "ok": bool(ok)}
 
 
 def margin_parity(cfg, dev, ids: np.ndarray, speech_emb: torch.Tensor):

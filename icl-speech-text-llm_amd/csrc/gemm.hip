@@ -671,6 +671,10 @@ static int gemm_impl(const icl_gemm_args* a, void* stream_, const RopeFuse* rope
   p.epi = a->epilogue; p.out_dtype = a->out_dtype; p.res_dtype = a->res_dtype;
   p.split_k = a->split_k;
   p.tiles_m = p.tiles_n = 0;
+  {
+    static const int env_gm = [] { const char* e = getenv("ICL_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();   // tuning knob (tools/gemm_ab.py)
+    p.group_m = env_gm;
+  }
 
   int tile = a->tile;
   if (tile == 0) tile = icl_gemm_select_tile(a->M, a->N, a->K, a->batch, a->split_k);

@@ -378,11 +378,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p_in, R
           *(f32x4*)(cbase + (int64_t)row * p.ldc * 4 + cc * 16) = v;
         }
       } else {
-        for (int c = tid; c < n_chunks; c += 512) {
-          const int row = c / chunks_per_row, cc = c - row * chunks_per_row;
-          const u32x4 v = *(const u32x4*)(smem + row * pitch + cc * 16);
-          *(u32x4*)(cbase + (int64_t)row * p.ldc * es + cc * 16) = v;
-        }
+        // all of a thread's row pieces are read from LDS first (independent reads in flight together), then stored: the loop
+        // form waited for each 16-B LDS read before issuing its store (16 dependent round trips per thread)
+        const int n_iter = n_chunks >> 9;                      // 8 | 16 (a compile-time constant per instantiation)
+        u32x4 v[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+          if (it < n_iter) {
+            const int c = tid + it * 512, row = c / chunks_per_row, cc = c - row * chunks_per_row;
+            v[it] = *(const u32x4*)(smem + row * pitch + cc * 16);
+          }
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+          if (it < n_iter) {
+            const int c = tid + it * 512, row = c / chunks_per_row, cc = c - row * chunks_per_row;
+            *(u32x4*)(cbase + (int64_t)row * p.ldc * es + cc * 16) = v[it];
+          }
       }
     }
     return;

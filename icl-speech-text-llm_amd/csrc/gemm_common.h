@@ -16,6 +16,7 @@ struct GemmParams {
   float* ws;
   int64_t lda, ldw, ldc, ldr, sA, sC, sR;
   int M, N, K, epi, out_dtype, res_dtype, split_k, tiles_m, tiles_n;
+  int group_m;   // M-tiles per super-tile of the block -> tile map (0 = GROUP_M)
 };
 
 constexpr int GROUP_M = 8;
@@ -144,10 +145,11 @@ __device__ __forceinline__ void block_to_tile(const GemmParams& p, int bid, int&
   const int nwg = p.tiles_m * p.tiles_n;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);   // bijective XCD remap
-  const int per_group = GROUP_M * p.tiles_n;
+  const int gm = p.group_m > 0 ? p.group_m : GROUP_M;
+  const int per_group = gm * p.tiles_n;
   const int group = wgid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = min(p.tiles_m - first_m, GROUP_M);
+  const int first_m = group * gm;
+  const int gsize = min(p.tiles_m - first_m, gm);
   const int in_group = wgid - group * per_group;
   tm = first_m + in_group % gsize;
   tn = in_group / gsize;

@@ -189,7 +189,7 @@ def salmonn_state(cfg: SalmonnCfg, seed: int = 0, device="cpu", dtype=torch.floa
     return sd
 
 
-def qwen_audio_state(cfg, seed: int = 0, device="cpu", dtype=torch.float32, jitter: bool = False) -> SD:
+def qwen_audio_state(cfg, seed: int = 0, device="cpu", dtype=torch.float32, jitter: bool = False, margin: bool = False) -> SD:
     """Synthetic Qwen2-Audio checkpoint under HF Qwen2AudioForConditionalGeneration names: ``audio_tower.*``,
     ``multi_modal_projector.linear.*``, ``language_model.model.*`` / ``language_model.lm_head.weight``."""
     g = _Gen(seed, device, dtype, jitter)
@@ -197,5 +197,5 @@ def qwen_audio_state(cfg, seed: int = 0, device="cpu", dtype=torch.float32, jitt
     sd.update(whisper_state(cfg.audio, g, prefix="audio_tower."))
     sd["multi_modal_projector.linear.weight"] = g.normal(cfg.llm.hidden, cfg.audio.d_model)
     sd["multi_modal_projector.linear.bias"] = g.bias(cfg.llm.hidden)
-    sd.update(llama_state(cfg.llm, g, prefix="language_model."))
+    sd.update(llama_state(cfg.llm, g, prefix="language_model.", margin=margin))
     return sd

@@ -98,8 +98,14 @@ def test_full_size_chain_matches_bf16_rounding_oracle(rt):
     rt7 = rt
     wav, ids = bench.synth_utterances(0, 1, cfg.llama.vocab)
     torch.set_num_threads(bench.host_cores())
-    par = bench.full_size_parity(cfg, host, rt7, dev, wav[0], ids[0])
+    # the pure-fp32 oracle (the reference's CPU behaviour) on the same utterance: stage outputs + first-step logits for the
+    # ratio criterion rel(gpu, fp32) <= 1.25 x rel(bf16-rounding oracle, fp32)
+    _, _, _, fp32_first, fp32_stages = bench.cpu_utterance(host, cfg, wav[0], ids[0], bench.host_cores())
+    par = bench.full_size_parity(cfg, host, rt7, dev, wav[0], ids[0], fp32_stages, fp32_first)
     print("full-size parity:", par)
+    assert par["ratio_ok"], {k: v.get("ratio_to_bf16_oracle_distance") for k, v in par["stages"].items()}
+    for name in ("whisper", "beats", "encode_speech", "first_step_logits"):
+        assert par["stages"][name]["ratio_to_bf16_oracle_distance"] <= bench.PARITY_RATIO, (name, par["stages"][name])
     emb0 = rt7.encode_speech(torch.from_numpy(wav[0])[None], [480000]).clone()[0]
     del host
     torch.cuda.empty_cache()

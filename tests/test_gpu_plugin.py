@@ -43,6 +43,32 @@ def test_generate_output_text_and_speech_fewshot(model):
     assert model.batch_counter == 2
 
 
+def test_one_overlong_row_costs_its_own_utterance_only(model):
+    """a prompt over max_pos fails ITS row, validated on the host before any launch — the other
+    rows of the batch are generated as if it were not there (the reference runs batch 1: one long prompt costs one utterance,
+    inference/inference.py:370-373).  Batch of 4, row 1 made 2600 byte-tokens long (tiny model: max_pos 2048)."""
+    b = _batch(model, "text", n=4, bs=4)
+    b = {k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    good = model.generate_ids(dict(b), want_first_logits=True)
+    assert good.dropped == () and model.last_dropped_rows == ()
+    long_b = dict(b, prompt=list(b["prompt"]))
+    long_b["prompt"][1] = long_b["prompt"][1] + " and more" * 330
+    res = model.generate_ids(long_b, want_first_logits=True)
+    assert res.dropped == (1,) and model.last_dropped_rows == (1,)
+    assert res.tokens.shape[0] == 4 and bool((res.tokens[1] == model.llama_tokenizer.pad_token_id).all())
+    assert torch.isnan(res.first_logits[1]).all() and torch.isfinite(res.first_logits[[0, 2, 3]]).all()
+    # the surviving rows are the ones the clean batch produced (prefill is batch invariant bit for bit: first-step logits equal)
+    assert torch.equal(res.first_logits[[0, 2, 3]], good.first_logits[[0, 2, 3]])
+    assert torch.equal(res.tokens[[0, 2, 3], 0], good.tokens[[0, 2, 3], 0])
+    out = model.generate_output(long_b)
+    assert len(out) == 4 and out[1] == "" and model.last_dropped_rows == (1,)
+    with pytest.raises(ValueError, match="exceed max_pos"):          # every row over the limit: nothing to run
+        model.generate_ids(dict(long_b, prompt=[long_b["prompt"][1]] * 4))
+    with pytest.raises(ValueError, match="exceed max_pos"):          # the runtime API's default stays strict
+        model.runtime.generate([[list(range(3, 203)) * 11]], None, max_new_tokens=10)
+    assert len(model.generate_output(dict(b))) == 4                  # and the model is usable afterwards
+
+
 def test_get_speech_embeddings_matches_oracle_batch1(model):
     from oracle import audio_frontend as af, models as om
     b = _batch(model, "speech", n=1, bs=1, num_examples=2, vary=True)

@@ -18,12 +18,25 @@ ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
 
 libs = []
-for spec in args.libs:
+for spec in args.libs:      # name=path[@ENV=value,...]: environment knobs a build reads once, at its first call (ICL_GEMM_GROUP_M)
     name, path = spec.split("=", 1) if "=" in spec else (os.path.basename(spec), spec)
+    path, _, envs = path.partition("@")
+    for kv in filter(None, envs.split(",")):
+        k, v = kv.split("=")
+        os.environ[k] = v
     lib = ctypes.CDLL(os.path.abspath(path))
     lib.icl_gemm_bf16.restype = ctypes.c_int
     lib.icl_gemm_bf16.argtypes = [ctypes.POINTER(B.GemmArgs), ctypes.c_void_p]
     lib.icl_last_error.restype = ctypes.c_char_p
+    if envs:                 # make the build read its knobs now, while they are set: one tiny call
+        _a = torch.zeros(256, 128, dtype=torch.bfloat16, device="cuda"); _c = torch.empty(256, 256, dtype=torch.bfloat16, device="cuda")
+        _g = B.GemmArgs(); _g.A, _g.W, _g.C = _a.data_ptr(), _a.data_ptr(), _c.data_ptr()
+        _g.lda = _g.ldw = 128; _g.ldc = 256; _g.M = _g.N = 256; _g.K = 128; _g.batch = 1; _g.split_k = 1; _g.tile = 1
+        _g.out_dtype, _g.res_dtype = B.ICL_BF16, B.ICL_F32
+        assert lib.icl_gemm_bf16(ctypes.byref(_g), torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        for kv in filter(None, envs.split(",")):
+            os.environ.pop(kv.split("=")[0], None)
     libs.append((name, lib))
 
 # (name, M, N, K, bias, gelu, residual(f32, in place), swiglu, out_f32)
