@@ -671,10 +671,7 @@ static int gemm_impl(const icl_gemm_args* a, void* stream_, const RopeFuse* rope
   p.epi = a->epilogue; p.out_dtype = a->out_dtype; p.res_dtype = a->res_dtype;
   p.split_k = a->split_k;
   p.tiles_m = p.tiles_n = 0;
-  {
-    static const int env_gm = [] { const char* e = getenv("ICL_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();   // tuning knob (tools/gemm_ab.py)
-    p.group_m = env_gm;
-  }
+  p.group_m = p.xcd_sync = 0;   // the 128x128 / 64x64 tiles keep GROUP_M; the 256x256 launcher picks per shape
 
   int tile = a->tile;
   if (tile == 0) tile = icl_gemm_select_tile(a->M, a->N, a->K, a->batch, a->split_k);

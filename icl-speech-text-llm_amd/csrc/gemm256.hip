@@ -5,6 +5,7 @@
 // branches, every accumulator fragment handled under each of them) and its epilogue ran from a cold instruction cache on
 // every tile.  The arithmetic of a path is unchanged by the specialisation — outputs are bit-identical.
 #include "gemm_common.h"
+#include <cstdlib>
 
 using namespace iclg;
 
@@ -324,6 +325,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p_in, R
     const int64_t c_col0 = swiglu ? (n0 >> 1) : n0;
     const bool one_round = ROPE || obf;                          // a bf16 tile fits whole: two barriers instead of four (two rounds
                                                                  // under GELU, to drain stores behind the second half's VALU work: no gain)
+    // f32 residual stream (always the two-round form): the residual rows of a half tile are whole-row 16-B loads, 16 per thread.
+    // They are issued a stage AHEAD of their use — half 0's before the first barrier and the C -> LDS writes, half 1's before
+    // half 0's row phase — so their latency (every CU reaches its epilogue at about the same time: a burst of 128 MB chip-wide)
+    // is covered by LDS work instead of being waited for twice; the accumulator halves they replace are dead by then.
+    f32x4 rrA[16], rrB[16];
+    auto load_res_rows = [&](int qa_, f32x4 (&rr)[16]) {
+      const char* rbase = (const char*)p.R + ((int64_t)z * p.sR + (int64_t)(m0 + qa_ * 128) * p.ldr + n0) * 4;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int c = tid + it * 512, row = c >> 6, cc = c & 63;
+        rr[it] = *(const f32x4*)(rbase + (int64_t)row * p.ldr * 4 + cc * 16);
+      }
+    };
+    if (has_res) load_res_rows(0, rrA);
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
       if (qa == 0 || !one_round) __syncthreads();                // K-tile reads (qa = 0) / the previous half's row reads are done
@@ -363,14 +378,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p_in, R
       }
       char* cbase = (char*)p.C + ((int64_t)z * p.sC + (int64_t)(m0 + (one_round ? 0 : qa * 128)) * p.ldc + c_col0) * es;
       const int n_chunks = (one_round ? 256 : 128) * chunks_per_row;   // a multiple of the 512 threads
-      if (has_res) {   // f32 residual stream: whole-row 16-B loads, all of a thread's 16 issued before the first use
-        const char* rbase = (const char*)p.R + ((int64_t)z * p.sR + (int64_t)(m0 + qa * 128) * p.ldr + n0) * 4;
-        f32x4 rr[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int c = tid + it * 512, row = c >> 6, cc = c & 63;
-          rr[it] = *(const f32x4*)(rbase + (int64_t)row * p.ldr * 4 + cc * 16);
-        }
+      if (has_res) {
+        if (qa == 0) load_res_rows(1, rrB);                      // the next half's residual rows, under this half's row phase
+        f32x4 (&rr)[16] = qa == 0 ? rrA : rrB;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
           const int c = tid + it * 512, row = c >> 6, cc = c & 63;
@@ -485,6 +495,19 @@ int launch256(const GemmParams& p, const dim3& grid, hipStream_t stream, const R
 int iclg::launch_tile256(GemmParams& p, int batch, hipStream_t stream, const RopeFuse* rope) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
+  {
+    // Super-tile height of the block -> tile map (gemm_common.h, block_to_tile): the XCD's window of ~32 concurrent tiles is
+    // gm M-tiles x 32/gm N-tiles.  Both shapes with gm + 32/gm = 12 fetch the same number of panels per window, but the A panels
+    // (256 rows x K, streamed from HBM, re-read by every window of their super-tile) are what has to survive in the Infinity
+    // Cache between windows while all eight XCDs stream: measured on the bench shapes (tools/gemm_ab.py, profiles/r03_gemm_ab.txt)
+    // the best gm keeps an XCD's A side near 8 MB — 1-2 at K = 11008, 3-4 at K = 4096-5120, 4-6 at K <= 1280; gm = 8 (rounds
+    // 1-2) cost 1.5-3.5 % at K >= 4096 and gm = 16 / 32 cost 8 / 16 %.
+    static const int env_gm = [] { const char* e = getenv("ICL_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();   // tuning knobs
+    static const int env_xs = [] { const char* e = getenv("ICL_GEMM_XCD_SYNC"); return e ? atoi(e) : 0; }();   // (tools/gemm_ab.py)
+    const int64_t panel = (int64_t)256 * p.K * 2;
+    p.group_m = env_gm > 0 ? env_gm : (int)std::min<int64_t>(6, std::max<int64_t>(1, 8400000 / panel));
+    p.xcd_sync = env_xs;
+  }
   const dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
   if (rope) return launch256<true, 0>(p, grid, stream, *rope);      // bf16 output, bias-only epilogue (checked by the caller)
   const RopeFuse none{};

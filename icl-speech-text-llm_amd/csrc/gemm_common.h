@@ -17,6 +17,7 @@ struct GemmParams {
   int64_t lda, ldw, ldc, ldr, sA, sC, sR;
   int M, N, K, epi, out_dtype, res_dtype, split_k, tiles_m, tiles_n;
   int group_m;   // M-tiles per super-tile of the block -> tile map (0 = GROUP_M)
+  int xcd_sync;  // block -> tile map variant (block_to_tile)
 };
 
 constexpr int GROUP_M = 8;
@@ -142,11 +143,30 @@ __device__ __forceinline__ bool tile_is_interior(const GemmParams& p, int m0, in
   return (m0 + BM <= p.M) && (n0 + BN <= p.N) && vec_path_ok(p);
 }
 __device__ __forceinline__ void block_to_tile(const GemmParams& p, int bid, int& tm, int& tn) {
+  // Blocks are dealt round-robin over the 8 XCDs (bid & 7 labels the XCD), each with its own L2.  Tiles are ordered in
+  // super-tiles of gm M-tiles x all N-tiles (M fastest), so the ~32 tiles an XCD runs together form a gm x 32/gm window
+  // sharing gm A panels and 32/gm W panels in that L2.
+  //   xcd_sync = 0: XCD x walks a contiguous 1/8 of the tile sequence (bijective for any tile count).
+  //   xcd_sync = 1: XCD x walks super-tiles x, x + 8, x + 16, ...: the eight XCDs sweep the SAME N range at the same time, each on
+  //                 its own M rows — a W panel is pulled into the Infinity Cache once and serves eight L2 fills while it is hot;
+  //                 the super-tiles past the last full round of eight fall back to the contiguous split (still bijective).
   const int nwg = p.tiles_m * p.tiles_n;
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);   // bijective XCD remap
   const int gm = p.group_m > 0 ? p.group_m : GROUP_M;
   const int per_group = gm * p.tiles_n;
+  int covered = 0;
+  if (p.xcd_sync) {
+    covered = ((p.tiles_m / gm) >> 3) * 8 * per_group;
+    if (bid < covered) {
+      const int x = bid & 7, j = bid >> 3;
+      const int r = j / per_group, i = j - r * per_group;
+      tm = (8 * r + x) * gm + i % gm;
+      tn = i / gm;
+      return;
+    }
+  }
+  const int nt = nwg - covered, b = bid - covered;
+  const int xcd = b & 7, q = nt >> 3, r = nt & 7;
+  const int wgid = covered + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);   // bijective XCD remap
   const int group = wgid / per_group;
   const int first_m = group * gm;
   const int gsize = min(p.tiles_m - first_m, gm);

@@ -14,6 +14,8 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--shapes", default="whisper,llama,beats")
 ap.add_argument("--scale-m", type=float, default=1.0, help="scale every M (e.g. 0.5 = micro-batch 128 shapes)")
+ap.add_argument("--blaslt", action="store_true", help="also time torch.mm (hipBLASLt) on the same operands, no epilogue: a "
+                "known-good reference for the main loop (guide rule 10), NOT part of the product")
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
 
@@ -101,6 +103,19 @@ for fam in args.shapes.split(","):
                 e1.record()
                 torch.cuda.synchronize()
                 times[nm].append(e0.elapsed_time(e1) / args.iters * 1e-3)
+        if args.blaslt:
+            wt = w.t()
+            torch.mm(a, wt)
+            torch.cuda.synchronize()
+            times["torch.mm"] = []
+            for _ in range(args.rounds):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    torch.mm(a, wt)
+                e1.record()
+                torch.cuda.synchronize()
+                times["torch.mm"].append(e0.elapsed_time(e1) / args.iters * 1e-3)
         fl = 2.0 * M * N * K
         cells = "  ".join(f"{nm}: {fl / statistics.median(t) / 1e12:7.1f} (best {fl / min(t) / 1e12:7.1f}) TF/s {statistics.median(t) * 1e6:8.1f} us"
                           for nm, t in times.items())
