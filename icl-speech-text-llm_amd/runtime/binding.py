@@ -58,6 +58,7 @@ _SIGNATURES = {
     "icl_last_error": (c_char_p, []),
     "icl_device_cu_count": (c_int, []),
     "icl_gemm_bf16": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "icl_gemm_rmsnorm_bf16": (c_int, [POINTER(GemmArgs), c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "icl_gemm_select_tile": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "icl_attn_fwd_bf16": (c_int, [POINTER(AttnArgs), c_void_p]),
     "icl_attn_decode_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
@@ -217,6 +218,32 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, resi
         GEMM_PROFILE.append((tile, split_k, 2.0 * g.M * N * g.K * batch, e0, e1, (g.M, N, g.K, batch)))
         return out
     launch()
+    return out
+
+
+def gemm_rmsnorm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, eps: float, xn: torch.Tensor, *,
+                 residual=None, split_k: int = 1, workspace=None, tile: int = 0, N=None, K=None) -> torch.Tensor:
+    """out = residual + a @ w.T (f32) and xn[:, :N] = bf16(rmsnorm(out) * gamma): the decode form of a projection back into the
+    residual stream followed by the next RMSNorm (icl_gemm_rmsnorm_bf16: with split_k > 1 one kernel reduces, adds, stores and
+    normalises)."""
+    _require_gpu(a, w, out, gamma, xn, residual, workspace)
+    lib = load_library()
+    g = GemmArgs()
+    N = w.shape[0] if N is None else N
+    g.A, g.W, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.bias, g.R, g.workspace = 0, _ptr(residual), _ptr(workspace)
+    g.lda, g.ldw, g.ldc = a.stride(-2), w.stride(0), out.stride(-2)
+    g.ldr = residual.stride(-2) if residual is not None else 0
+    g.strideA = g.strideC = g.strideR = 0
+    g.M, g.N, g.K, g.batch = a.shape[-2], N, (w.shape[1] if K is None else K), 1
+    g.epilogue = EPI_RESIDUAL if residual is not None else 0
+    g.out_dtype, g.res_dtype, g.split_k = _dt(out), ICL_F32, split_k
+    g.tile = tile if tile else lib.icl_gemm_select_tile(g.M, N, g.K, 1, split_k)
+    assert out.dtype == torch.float32 and xn.dtype == torch.bfloat16 and gamma.dtype == torch.float32
+    if split_k > 1 and workspace is not None:
+        assert workspace.dtype == torch.float32 and workspace.numel() >= split_k * g.M * N
+    _check(lib.icl_gemm_rmsnorm_bf16(ctypes.byref(g), gamma.data_ptr(), eps, xn.data_ptr(), xn.stride(0), _stream()),
+           "icl_gemm_rmsnorm_bf16")
     return out
 
 

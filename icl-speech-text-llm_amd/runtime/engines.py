@@ -346,6 +346,7 @@ class SpeechQFormerHIP:
 # ================================================================================================
 class LlamaHIP:
     decode_packed_weights = True     # micro-batch <= 256: decode GEMMs stream decode-packed copies of the layer weights
+    fuse_decode_norms = True         # decode: o_proj / down_proj + the RMSNorm that follows them in one call (icl_gemm_rmsnorm_bf16)
 
     def __init__(self, w: PackedLlama, device, decode_packed: Optional[bool] = None, pack_now: bool = True):
         """``decode_packed`` (default: the class attribute): keep a second, decode-packed layout of the layer weights (+12.9 GB
@@ -375,7 +376,11 @@ class LlamaHIP:
 
     # ---- one decoder layer over M packed rows ---------------------------------------------------
     def _layer(self, ws: Workspace, L, h, M: int, tag: str, attn_fn, pos, seq_ids, kc, vc, max_len: int,
-               split: Optional[dict] = None, kv_rows_to_c: bool = True):
+               split: Optional[dict] = None, kv_rows_to_c: bool = True, xn_ready: bool = False, next_norm=None):
+        """``xn_ready``: the previous call has already written this layer's normalised input (decode: fused into the reduction
+        of the previous down_proj).  ``next_norm`` = (gamma, out bf16 [M, >= hidden]) of the RMSNorm that follows this layer
+        (the next layer's input norm into the same ``xn`` buffer, or the final norm): decode fuses it into the down_proj's
+        split-K reduction, as it does the post-attention norm into the o_proj's (icl_gemm_rmsnorm_bf16)."""
         c, w = self.w.cfg, self.w
         hd, I, D, H = c.hidden, c.ffn, c.head_dim, c.n_heads
         xn = ws.get(tag + "xn", (M, w.k_aug), BF16, zero=True)   # augmentation tail stays zero
@@ -385,7 +390,8 @@ class LlamaHIP:
         sk = split or {}
         nsplit = max([v for k, v in sk.items() if k != "tile"], default=1)
         wsk = ws.get(tag + "splitk", (nsplit * M * max(3 * hd, 2 * I),), F32) if nsplit > 1 else None
-        B.rmsnorm(h, L.rms1, xn, c.rms_eps, N=hd)
+        if not xn_ready:
+            B.rmsnorm(h, L.rms1, xn, c.rms_eps, N=hd)
         if L.lora_a is not None:   # x_aug[:, hd:hd+2r] = x @ (s*A)^T : a skinny GEMM for prefill, a GEMV-style kernel for decode
             # prefill: always the 64x64 tile (the choice must not depend on the batch, or rows would not be batch-invariant);
             # decode: the skinny kernel (one block, K split over its 8 waves) up to 64 rows, the block-per-row kernel above
@@ -405,13 +411,23 @@ class LlamaHIP:
             B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
         attn_fn(qkv, att)
         dp = L.decode_packed if sk.get("tile") in (5, 6) else None    # (wqkv, wo, wgu, wdown) in the decode kernels' layout
-        B.gemm(att, dp[1] if dp else L.wo, h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=sk.get("tile", 0),
-               N=hd, K=hd)
-        B.rmsnorm(h, L.rms2, xn, c.rms_eps, N=hd)
+        fuse = split is not None and self.fuse_decode_norms
+        if fuse:     # decode: h += att Wo^T and the post-attention RMSNorm in one call (one kernel when the GEMM is split-K)
+            B.gemm_rmsnorm(att, dp[1] if dp else L.wo, h, L.rms2, c.rms_eps, xn, residual=h, split_k=sk.get("o", 1),
+                           workspace=wsk, tile=sk.get("tile", 0), N=hd, K=hd)
+        else:
+            B.gemm(att, dp[1] if dp else L.wo, h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=sk.get("tile", 0),
+                   N=hd, K=hd)
+            B.rmsnorm(h, L.rms2, xn, c.rms_eps, N=hd)
         B.gemm(xn, dp[2] if dp else L.wgu, act, swiglu=True, K=hd, split_k=sk.get("gu", 1), workspace=wsk,
                tile=sk.get("tile", 0), N=2 * I)
+        if fuse and next_norm is not None:
+            B.gemm_rmsnorm(act, dp[3] if dp else L.wdown, h, next_norm[0], c.rms_eps, next_norm[1], residual=h,
+                           split_k=sk.get("down", 1), workspace=wsk, tile=sk.get("tile", 0), N=hd, K=I)
+            return True
         B.gemm(act, dp[3] if dp else L.wdown, h, residual=h, split_k=sk.get("down", 1), workspace=wsk,
                tile=sk.get("tile", 0), N=hd, K=I)
+        return False
 
     # ---- K10: prefill over ragged packed sequences ------------------------------------------------
     def prefill(self, ws: Workspace, h: torch.Tensor, seq_lens: List[int], cache: Optional["KVCache"] = None) -> torch.Tensor:
@@ -448,13 +464,15 @@ class LlamaHIP:
                         kv_rows_to_c=not kv_from_cache)
         return h
 
-    def logits(self, ws: Workspace, h_rows: torch.Tensor, name: str = "ll_logits") -> torch.Tensor:
-        """h_rows f32 [R, hidden] -> logits f32 [R, vocab] (final RMSNorm + lm_head)."""
+    def logits(self, ws: Workspace, h_rows: torch.Tensor, name: str = "ll_logits", xn_ready: bool = False) -> torch.Tensor:
+        """h_rows f32 [R, hidden] -> logits f32 [R, vocab] (final RMSNorm + lm_head).  ``xn_ready``: the final norm has been
+        written into ``name + "_xn"`` already (decode: fused into the last down_proj's reduction)."""
         c = self.w.cfg
         R = h_rows.shape[0]
         xn = ws.get(name + "_xn", (R, c.hidden), BF16)
         out = ws.get(name, (R, c.vocab), F32)
-        B.rmsnorm(h_rows, self.w.norm, xn, c.rms_eps)
+        if not xn_ready:
+            B.rmsnorm(h_rows, self.w.norm, xn, c.rms_eps)
         B.gemm(xn, self.w.lm_head, out, tile=4 if R <= 8 else 0)
         return out
 
@@ -491,14 +509,20 @@ class LlamaHIP:
             split = dict(qkv=sk(3 * c.hidden, self.w.k_aug), o=sk(c.hidden, c.hidden), gu=sk(2 * c.ffn, c.hidden),
                          down=sk(c.hidden, c.ffn), tile=2)
 
-        for i, L in enumerate(self.w.layers):
+        layers = self.w.layers
+        xn_next = ws.get("dc_xn", (Bn, self.w.k_aug), BF16, zero=True)          # the layers' normalised-input buffer (_layer's tag + "xn")
+        xn_final = ws.get("dc_logits_xn", (Bn, c.hidden), BF16)
+        ready = False
+        for i, L in enumerate(layers):
             kc, vc = cache.k[i], cache.v[i]
 
             def attn(qkv, att, kc=kc, vc=vc):
                 B.attn_decode(qkv[:, :c.hidden], kc, vc, att, lens, H, D, cache.max_len, D ** -0.5)
 
-            self._layer(ws, L, h, Bn, "dc_", attn, pos, sid, kc, vc, cache.max_len, split=split)
-        return self.logits(ws, h, name="dc_logits")
+            nxt = (layers[i + 1].rms1, xn_next) if i + 1 < len(layers) else (self.w.norm, xn_final)
+            ready = self._layer(ws, L, h, Bn, "dc_", attn, pos, sid, kc, vc, cache.max_len, split=split, xn_ready=ready,
+                                next_norm=nxt)
+        return self.logits(ws, h, name="dc_logits", xn_ready=ready)
 
 
 class KVCache:

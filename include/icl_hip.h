@@ -95,6 +95,14 @@ typedef struct icl_gemm_args {
 } icl_gemm_args;
 
 int icl_gemm_bf16(const icl_gemm_args* args, void* stream);
+/* The decode form of "projection back into the residual stream, then the next RMSNorm" (HF LlamaDecoderLayer:
+ * hidden = residual + o_proj(attn) ; post_attention_layernorm(hidden) — and down_proj followed by the next layer's
+ * input_layernorm / the final norm; reached from models/custom_salmon.py:704-720 through generate): C = R + A W^T in f32
+ * (epilogue must be 0 or ICL_EPI_RESIDUAL with an f32 residual, batch 1, f32 output) AND xn[m][:N] = bf16(rmsnorm(C[m]) * gamma).
+ * With split_k > 1 the partial slabs are reduced, the residual added, the row stored and normalised by ONE kernel (a launch
+ * and a re-read of the row less than icl_gemm_bf16 + icl_rmsnorm; C is bit-identical to that pair, xn sums its squares in a
+ * different — fixed — order); with split_k == 1 it is exactly that pair.  No reference counterpart (fusion). */
+int icl_gemm_rmsnorm_bf16(const icl_gemm_args* args, const float* gamma, float eps, void* xn, int64_t ld_xn, void* stream);
 /* Decode-packed copy of a weight matrix for tile 5: row-major bf16 W [N][ldw] -> out, (ceil(N/16)*16) x K bf16
  * elements: per 16-row block a K-long stream of 1-KB pieces (one per 32-wide k-step) in MFMA operand order, so that the
  * decode kernel's wave-loads are 1 KB contiguous (rows >= N are zero).  A layout copy made once at load time (the

@@ -745,6 +745,34 @@ def test_gemm_m128_decode_kernel(B, M, N, K, split):
     assert (out[:M] - out2).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,split,tile", [(256, 4096, 1024, 8, 5), (130, 4096, 2048, 4, 5), (37, 5120, 1024, 2, 5), (256, 4096, 512, 1, 5),
+                                              (300, 4096, 1024, 4, 2), (5, 4096, 1024, 1, 6)])
+def test_gemm_rmsnorm_decode_fusion(B, M, N, K, split, tile):
+    """icl_gemm_rmsnorm_bf16 (decode: projection back into the residual stream + the RMSNorm that follows, the split-K
+    reduction, residual add, row store and normalisation in ONE kernel): the f32 row must be bit-identical to icl_gemm_bf16
+    with the same split, the normalised row equal to icl_rmsnorm of it up to the summation order of its sum of squares
+    (fixed, but four wave sums instead of one wave per row: <= 1 bf16 ulp on a few elements), in place over the residual."""
+    a, w = _rand_bf16(M, K, seed=171, scale=0.5), _rand_bf16(N, K, seed=172, scale=0.05)
+    res = torch.randn(M, N, device=DEV)
+    gamma = 1.0 + 0.1 * torch.randn(N, device=DEV)
+    ws = torch.empty(split * M * N, device=DEV) if split > 1 else None
+    wt = B.pack_decode_weights(w) if tile in (5, 6) else w
+    h_ref = res.clone()
+    B.gemm(a, wt, h_ref, residual=h_ref, tile=tile, split_k=split, workspace=ws, N=N)
+    xn_ref = torch.empty(M, N + 64, dtype=torch.bfloat16, device=DEV)
+    B.rmsnorm(h_ref, gamma, xn_ref, 1e-5, N=N)
+    h = res.clone()
+    xn = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    B.gemm_rmsnorm(a, wt, h, gamma, 1e-5, xn, residual=h, tile=tile, split_k=split, workspace=ws, N=N)
+    assert torch.equal(h, h_ref)
+    assert bool((xn[:, N:] == 7.0).all())                          # the LoRA augmentation columns are not touched
+    d = (xn[:, :N].float() - xn_ref[:, :N].float()).abs()
+    ulp = xn_ref[:, :N].float().abs() * 2.0 ** -7
+    assert bool((d <= ulp + 1e-30).all()) and float((d > 0).float().mean()) < 0.02
+    ref = torch.nn.functional.rms_norm(h_ref, (N,), gamma, 1e-5)
+    assert _relerr(xn[:, :N], ref) < 4e-3
+
+
 def test_gemm_m128_rows_do_not_depend_on_the_block_height(B):
     """A row's sums are the same MFMAs in the same order whether it is computed in a 64-, 128- or 256-row block: decoding two
     micro-batches together must not change a sequence's logits."""
