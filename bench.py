@@ -696,7 +696,7 @@ def main():
         dom = max(per_tile, key=lambda k: per_tile[k][1])          # dominant kernel = largest share of GPU time
         fl, tt, n = per_tile[dom]
         traffic, traffic_src = None, None
-        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:   # HBM-side bytes per launch of this kernel from the committed PMC passes of this same command (profiles/)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 key = {1: "gemm_bf16_kernel<2, 2, 4, 4>", 2: "gemm_bf16_kernel<2, 2, 2, 2>", 3: "gemm256_bf16_kernel"}[dom]
@@ -713,8 +713,9 @@ def main():
                 f"passes of this command (profiles/{traffic_src}); the counters sit at the L2<->fabric boundary and "
                 "include Infinity-Cache hits" if traffic else None, "launches": n, "avg_launch_us": round(tt / n * 1e6, 2),
                 "avg_launch_gflop": round(fl / n / 1e9, 3), "share_of_step_time": round(tt / elapsed, 3),
-                "clock_note": "peak is the nominal 2.4 GHz figure; under this kernel the chip holds 1.34-1.61 GHz (s_memtime stamps, "
-                              "profiles/r02_gemm_phase_stamps.txt), where its main loop keeps the matrix pipe 92 % busy in cycles",
+                "clock_note": "peak is the nominal 2.4 GHz figure; SQ counters over the bench's own launches (profiles/r03_pmc_sq_*.json: "
+                              "SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) read 75-80 % matrix-pipe busy at ~1.75 GHz on the K >= 4096 shapes, "
+                              "51-63 % at ~1.9 GHz on the K = 1280 shapes: busy x clock / 2.4 GHz reproduces this fraction",
                 "all_gemm_share_of_step_time": round(all_t / elapsed, 3),
                 "other_gemm_kernels": {names.get(k, str(k)): {"achieved_tflops": round(v[0] / v[1] / 1e12, 1),
                                                              "share_of_step_time": round(v[1] / elapsed, 3), "launches": v[2]}
