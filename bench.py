@@ -104,6 +104,8 @@ def parse():
     ap.add_argument("--no-through-plugin", action="store_true", help="skip the plugin-path leg")
     ap.add_argument("--plugin-workers", type=int, default=8)
     ap.add_argument("--plugin-batch", type=int, default=None, help="batch size of the plugin-path leg (default: --batch, the micro-batch of the runtime number)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the BASELINE.json configs 4 and 5 (1-GPU halves) that the default N = 1 run appends after the headline legs")
     ap.add_argument("--workload", default="c2", choices=["c2", "c2s", "c4", "c5"],
                     help="BASELINE.md §4: c2 = headline (default); c2s = 5 speech exemplars; c4 = Qwen2-Audio HVB; "
                          "c5 = Llama2-13B VOXCELEB+HVB+VOXPOPULI round-robin")
@@ -537,6 +539,56 @@ def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batche
                            "times are bracketed by barriers, utt_per_s = all ranks' utterances / MAX over ranks of the wall time"}
 
 
+def quick_workload(wl: str, dev, batch: int = 64, steps: int = 3, warmup: int = 1):
+    """One of the non-headline workloads of BASELINE.md §4, in THIS process (a process that has initialised the GPU must not
+    start GPU children): build the seeded model, keep `warmup + steps` micro-batches resident, two untimed passes for the decode
+    graph, then time `steps` passes.  Same step definition as the headline loop (encoders -> prefill -> 10 greedy tokens)."""
+    from icl_speech_text_llm_amd.runtime import synth
+    from icl_speech_text_llm_amd.runtime.config import QwenAudioCfg, SalmonnCfg
+    wl_desc, wl_text, wl_naudio = WORKLOADS[wl]
+    is_qwen = wl == "c4"
+    t_build = time.perf_counter()
+    if is_qwen:
+        from icl_speech_text_llm_amd.runtime.qwen import QwenAudioRuntime
+        cfg = QwenAudioCfg()
+        rt = QwenAudioRuntime(cfg, synth.qwen_audio_state(cfg, seed=0, device=dev, dtype=torch.bfloat16), device=dev, consume=True)
+        vocab, audio_tokens = cfg.llm.vocab, 750
+    else:
+        from icl_speech_text_llm_amd.runtime.salmonn import SalmonnRuntime
+        cfg = SalmonnCfg.llama2_13b() if wl == "c5" else SalmonnCfg.llama2_7b()
+        rt = SalmonnRuntime(cfg, synth.salmonn_state(cfg, seed=0, device=dev, dtype=torch.bfloat16), device=dev, consume=True)
+        vocab, audio_tokens = cfg.llama.vocab, N_AUDIO_TOK
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    wavs, prompts = [], []
+    lens = [480000] * (batch * wl_naudio)
+    for s_ in range(warmup + steps):
+        w, pr = synth_workload(s_ * batch, batch, vocab, wl_text, wl_naudio, audio_tokens)
+        wavs.append(torch.from_numpy(w).to(dev))
+        prompts.append(pr)
+
+    def step(s_):
+        speech = rt.encode_audio(raw_wav=wavs[s_], wav_lens=lens)[0] if is_qwen else rt.encode_speech(wavs[s_], lens)
+        return rt.generate(prompts[s_], speech, max_new_tokens=NEW_TOKENS, suppress_eos=True).tokens
+    for s_ in range(max(warmup, 2)):          # eager pass + capture pass of the decode graph, before the clock
+        step(min(s_, warmup + steps - 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(warmup, warmup + steps):
+        toks = step(s_)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": wl_desc, "value": round(batch * steps / dt, 2), "unit": "utterances/s", "ms_per_step": round(dt / steps * 1e3, 1),
+           "utterances_per_step": batch, "steps": steps,
+           "prompt_positions": [t + wl_naudio * audio_tokens for t in wl_text] if len(wl_text) > 1 else wl_text[0] + wl_naudio * audio_tokens,
+           "new_tokens": int(toks.shape[1]), "workspace_gib": round(rt.ws.nbytes() / 2 ** 30, 1), "build_s": round(t_build, 1)}
+    del rt, wavs
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     launch_ranks(args)
@@ -848,6 +900,25 @@ def main():
                 cb["tokens_match_gpu_on_margin_weights"] = par["margin_weights"]["tokens_match"]
                 out["parity"] = par
                 parity_failed = not par["ok"]
+        if world == 1 and args.workload == "c2" and not args.tiny and not args.no_other_workloads:
+            # last: the parent's model, workspace and side models are released first (the children build their own)
+            try:
+                del rt
+            except Exception:
+                pass
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_workloads"] = {"note": "BASELINE.json configs 4 and 5 (the 1-GPU half of 5) on this box, micro-batch 64, 3 timed steps "
+                                              "each after the graph warm-up, same step definition; run after the headline legs in this process"}
+            for wl in ("c4", "c5"):
+                log(f"other workload {wl} ...")
+                try:
+                    out["other_workloads"][wl] = quick_workload(wl, dev)
+                except Exception as e:      # a reported side number must never cost the headline line
+                    out["other_workloads"][wl] = {"error": f"{type(e).__name__}: {e}"}
+                    torch.cuda.empty_cache()
+                log(f"other workload {wl}: {out['other_workloads'][wl]}")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
