@@ -694,6 +694,37 @@ def _signature_table(fn):
     return out
 
 
+def g16_beam_search():
+    """HF beam search with inputs_embeds only, for the knobs the reference forwards (custom_salmon.py:709-714: num_beams,
+    length_penalty, min_length=1; early_stopping stays at its default False) on the miniature Llama of ``llama_tiny.npz``."""
+    m = _tiny_llama()
+    torch.manual_seed(3)
+    emb = torch.randn(2, 23, 64) * 0.5            # the same prompts as llama_tiny.npz (same seed, same order of draws)
+    att = torch.ones(2, 23, dtype=torch.long)
+    out = {}
+
+    def run(name, e, num_beams, lp, eos, max_new=10):
+        with torch.no_grad():
+            r = m.generate(inputs_embeds=e, attention_mask=att[: e.shape[0]], max_new_tokens=max_new, do_sample=False,
+                           num_beams=num_beams, min_length=1, length_penalty=lp, pad_token_id=259, eos_token_id=eos,
+                           return_dict_in_generate=True, output_scores=True)
+        out[name + "_seq"], out[name + "_score"] = r.sequences, r.sequences_scores
+        out[name + "_knobs"] = np.array([num_beams, lp, -1 if eos is None else eos, max_new], dtype=np.float64)
+        return r.sequences
+
+    free = run("free4", emb, 4, 1.0, None)
+    run("free3_lp2", emb, 3, 2.0, None)
+    run("free2_lp0", emb, 2, 0.0, None)
+    # an EOS the best hypothesis of row 0 meets at step 3 / at step 0; one both rows meet early; one single row
+    run("eos_mid4", emb, 4, 1.0, int(free[0, 3]))
+    run("eos_first4", emb, 4, 1.0, int(free[0, 0]))
+    run("eos_mid4_lpneg", emb, 4, -1.0, int(free[1, 2]))
+    run("eos_mid5_lp2", emb, 5, 2.0, int(free[1, 4]))
+    run("one_row_eos3", emb[1:], 3, 1.0, int(free[1, 1]))
+    run("short3", emb, 3, 1.0, int(free[0, 1]), max_new=3)
+    save("beam_tiny.npz", **out)
+
+
 def g15_boundary():
     """The plugin boundary as the reference declares it: inspect.signature of BaseModel's public methods,
     ModelFactory's static methods, CustomSALMONN / CustomQwen constructors and entry points, and the action table of the
@@ -775,3 +806,4 @@ if __name__ == "__main__":
     g13_performance_tracker()
     g14_reference_glue_sentencepiece()
     g15_boundary()
+    g16_beam_search()

@@ -72,6 +72,28 @@ def test_llama_forward_loss_and_generate_match_hf():
     assert g0.tolist() == a["gen_eos0"].tolist() and g0.shape == (1, 1)
 
 
+BEAM_CASES = ["free4", "free3_lp2", "free2_lp0", "eos_mid4", "eos_first4", "eos_mid4_lpneg", "eos_mid5_lp2", "one_row_eos3",
+              "short3"]
+
+
+@pytest.mark.parametrize("case", BEAM_CASES)
+def test_beam_search_matches_hf(case):
+    """oracle.generate_beam == HF generate(inputs_embeds, num_beams=K, length_penalty=...) on the miniature Llama: returned
+    hypothesis (pad-filled after its EOS) and its length-penalised score."""
+    from oracle import models as om
+    a, sd = _load("llama_tiny.npz")
+    g = np.load(os.path.join(G, "beam_tiny.npz"))
+    llm = om.LlamaOracle(sd, n_heads=2, rms_eps=1e-5)
+    emb = torch.from_numpy(a["emb"])
+    K, lp, eos, max_new = g[case + "_knobs"]
+    want = g[case + "_seq"]
+    e = emb[1:] if want.shape[0] == 1 else emb
+    ids, score = llm.generate_beam(e, int(max_new), eos_id=int(eos), pad_id=259, num_beams=int(K), length_penalty=float(lp),
+                                   return_scores=True)
+    assert ids.tolist() == want.tolist()
+    assert np.abs(score.numpy() - g[case + "_score"]).max() < 2e-4 * max(1.0, float(np.abs(g[case + "_score"]).max()))
+
+
 @pytest.mark.parametrize("case", ["text_only", "speech_text_ex", "speech_speech_ex", "sqa_speech_text_ex",
                                   "sqa_speech_speech_ex", "sqa_speechtext_zero"])
 def test_prompt_wrap_labels_logits_generate_match_reference_glue(case):
