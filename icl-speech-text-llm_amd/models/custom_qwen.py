@@ -255,13 +255,14 @@ class CustomQwen(BaseModel):
         # generation_config.json (custom_qwen.py:227-233), which is not reachable here: greedy by default; ``generation_config``
         # (constructor kwarg or batch keys) switches on the sampled tail with the same kernel as the SALMONN path.
         g = {**self.generation_config, **{k: batch[k] for k in ("do_sample", "temperature", "top_p", "top_k", "repetition_penalty",
-                                                                   "generator") if k in batch}}
+                                                                   "generator", "num_beams", "length_penalty") if k in batch}}
         res = self.runtime.generate(segs, speech, max_new_tokens=int(batch.get("max_new_tokens", 10)),
                                     eos_id=self.cfg.llm.eos_id, pad_id=self.cfg.llm.pad_id,
                                     do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),
                                     top_p=float(g.get("top_p", 1.0)), top_k=int(g.get("top_k", 50)),
                                     repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"),
-                                    want_first_logits=want_first_logits, overlong="drop")
+                                    want_first_logits=want_first_logits, overlong="drop", num_beams=int(g.get("num_beams", 1)),
+                                    length_penalty=float(g.get("length_penalty", 1.0)))
         self.last_dropped_rows = tuple(res.dropped)      # rows over max_pos cost their own utterance only (see CustomSALMONN)
         if res.dropped:
             logger.error("rows %s of this batch were not generated: prompt + new tokens exceed max_pos %d", list(res.dropped),

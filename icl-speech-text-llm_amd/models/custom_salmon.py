@@ -530,8 +530,6 @@ class CustomSALMONN(BaseModel):
         """The arithmetic half of ``generate_output``: batch dict -> ``GenerateResult`` (new token ids int64 [B, width] with HF's
         EOS / pad / width rules, and the first-step logits f32 [B, V] on request).  The data-parallel CLI gathers these as
         fixed-shape tensors and decodes on rank 0."""
-        if samples.get("num_beams", 1) != 1:
-            raise NotImplementedError("the MI355X path implements greedy search and sampling, not beam search (num_beams=1)")
         t0 = time.perf_counter()
         samples = self._host_counts(samples)
         speech_embeds, _, example_embeds, _ = self.get_speech_embeddings(samples)
@@ -539,8 +537,8 @@ class CustomSALMONN(BaseModel):
         num_examples = samples.get("num_examples", torch.zeros(len(samples["prompt"]), dtype=torch.long))
         segs, speech = self._segments(speech_embeds, samples["prompt"], num_examples, example_embeds)
         t2 = time.perf_counter()
-        # generation knobs and their defaults as the reference reads them (:708-715); min_length / length_penalty have no
-        # effect on this path (min_length is a no-op with inputs_embeds, length_penalty only acts on beams)
+        # generation knobs and their defaults as the reference reads them (:708-715); min_length is a no-op with inputs_embeds
+        # and length_penalty only acts on beams (num_beams > 1: HF beam search, early_stopping at its default False)
         res = self.runtime.generate(segs, speech, max_new_tokens=int(samples.get("max_new_tokens", 10)),
                                     eos_id=self.llama_tokenizer.eos_token_id, pad_id=self.llama_tokenizer.pad_token_id,
                                     do_sample=bool(samples.get("do_sample", False)),
@@ -548,7 +546,8 @@ class CustomSALMONN(BaseModel):
                                     top_k=int(samples.get("top_k", 50)),
                                     repetition_penalty=float(samples.get("repetition_penalty", 1.0)),
                                     generator=samples.get("generator"), want_first_logits=want_first_logits,
-                                    overlong="drop")
+                                    overlong="drop", num_beams=int(samples.get("num_beams", 1)),
+                                    length_penalty=float(samples.get("length_penalty", 1.0)))
         # a prompt over max_pos costs ITS utterance, not the batch (the reference runs batch 1: inference/inference.py:370-373);
         # such rows come back pad-filled and are listed here for the caller (the CLI reports them as missing indices)
         self.last_dropped_rows = tuple(res.dropped)

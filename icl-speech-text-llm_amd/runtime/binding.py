@@ -79,6 +79,11 @@ _SIGNATURES = {
     "icl_sample_eos": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int32,
                                c_float, c_float, c_int32, c_float, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "icl_beam_step": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "icl_kv_copy_spans_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                       c_void_p]),
     "icl_logmel_whisper": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
                                    c_void_p, c_int64, c_void_p, c_void_p]),
     "icl_spec_to_xt": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
@@ -366,6 +371,57 @@ def sample_eos(logits, work, uniforms, eos_id: int, pad_id: int, finished, out_t
                                          repetition_penalty, temperature, top_k, top_p, uniforms.data_ptr(), eos_id, pad_id,
                                          finished.data_ptr(), out_tokens.data_ptr(), out_tokens.stride(0), step,
                                          next_ids.data_ptr(), dbg[0], dbg[1], dbg[2], dbg[3], _stream()), "icl_sample_eos")
+
+
+class BeamState:
+    """Device-resident state of ``icl_beam_step`` for B rows x K beams x T new tokens (see include/icl_hip.h)."""
+
+    def __init__(self, get, B: int, K: int, T: int, pad_id: int):
+        f32, i32 = torch.float32, torch.int32
+        self.B, self.K, self.T = B, K, T
+        self.run_score, self.fin_score = get("gen_beam_run_score", (B, K), f32), get("gen_beam_fin_score", (B, K), f32)
+        self.run_seq, self.fin_seq = get("gen_beam_run_seq", (B, K, T), i32), get("gen_beam_fin_seq", (B, K, T), i32)
+        self.fin_len, self.fin_flag = get("gen_beam_fin_len", (B, K), i32), get("gen_beam_fin_flag", (B, K), i32)
+        self.unsat = get("gen_beam_unsat", (B,), i32)
+        self.next_ids, self.parent = get("gen_beam_next", (B * K,), i32), get("gen_beam_parent", (B * K,), i32)
+        self.run_score.fill_(-1.0e9)
+        self.run_score[:, 0] = 0.0
+        self.fin_score.fill_(-1.0e9)
+        self.run_seq.fill_(pad_id)
+        self.fin_seq.fill_(pad_id)
+        self.fin_len.zero_()
+        self.fin_flag.zero_()
+        self.unsat.fill_(1)
+
+
+def beam_step(logits, state: BeamState, step: int, eos_id: int, length_penalty: float, V=None):
+    """One beam-search step over ``logits`` f32 [B, V] (step 0: the prompt's distribution, shared by the K beams) or
+    [B * K, V] (row b * K + k = running beam k of row b)."""
+    _require_gpu(logits, state.run_score)
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    rows = logits.shape[0] // state.B
+    assert rows * state.B == logits.shape[0] and rows in (1, state.K)
+    _check(load_library().icl_beam_step(logits.data_ptr(), logits.stride(0), rows, state.B,
+                                        logits.shape[1] if V is None else V, state.K, state.T, step, eos_id,
+                                        float(length_penalty), state.run_score.data_ptr(), state.run_seq.data_ptr(),
+                                        state.fin_score.data_ptr(), state.fin_seq.data_ptr(), state.fin_len.data_ptr(),
+                                        state.fin_flag.data_ptr(), state.unsat.data_ptr(), state.next_ids.data_ptr(),
+                                        state.parent.data_ptr(), _stream()), "icl_beam_step")
+
+
+def kv_copy_spans(src, dst, n_rows: int, *, src_seq=None, src_t0=None, dst_seq=None, dst_t0=None, n_t=None, n_fixed: int = 0):
+    """src / dst: bf16 [layers][seqs][heads][positions][head_dim] (any strides on the first three dims); copies, per row r,
+    layer and head, ``n_t[r]`` (or ``n_fixed``) positions from (src_seq[r], src_t0[r]) to (dst_seq[r], dst_t0[r])."""
+    _require_gpu(src, dst, src_seq, src_t0, dst_seq, dst_t0, n_t)
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16 and src.dim() == 5 and dst.dim() == 5
+    assert src.stride(4) == 1 and dst.stride(4) == 1 and src.stride(3) == src.shape[4] and dst.stride(3) == dst.shape[4]
+    assert src.shape[0] == dst.shape[0] and src.shape[2] == dst.shape[2] and src.shape[4] == dst.shape[4]
+    for t in (src_seq, src_t0, dst_seq, dst_t0, n_t):
+        assert t is None or (t.dtype == torch.int32 and t.numel() >= n_rows)
+    _check(load_library().icl_kv_copy_spans_bf16(src.data_ptr(), dst.data_ptr(), src.stride(0), src.stride(1), src.stride(2),
+                                                 dst.stride(0), dst.stride(1), dst.stride(2), _ptr(src_seq), _ptr(src_t0),
+                                                 _ptr(dst_seq), _ptr(dst_t0), _ptr(n_t), n_fixed, n_rows, src.shape[0],
+                                                 src.shape[2], src.shape[4], _stream()), "icl_kv_copy_spans_bf16")
 
 
 def logmel_whisper(wav, wav_lens, mel_filters, n_mel: int, spec, xt, workspace):

@@ -125,7 +125,8 @@ class CausalLMRuntimeMixin:
                  pad_id: Optional[int] = None, suppress_eos: bool = False, want_first_logits: bool = False,
                  cache_len_multiple: int = 64, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
                  top_k: int = 50, repetition_penalty: float = 1.0, generator: Optional[torch.Generator] = None,
-                 sample_debug=None, want_step_logits: bool = False, overlong: str = "raise") -> GenerateResult:
+                 sample_debug=None, want_step_logits: bool = False, overlong: str = "raise", num_beams: int = 1,
+                 length_penalty: float = 1.0, beam_debug: Optional[dict] = None) -> GenerateResult:
         """Greedy search with HF ``generate(inputs_embeds=…)`` semantics (models/custom_salmon.py:704-720): returns only
         the new tokens; a row that has emitted EOS is filled with pad; the width is that of the longest row
         (``min_length`` is a no-op with inputs_embeds).  All steps are enqueued without a host sync; the
@@ -140,7 +141,9 @@ class CausalLMRuntimeMixin:
         ``overlong``: a row whose prompt + ``max_new_tokens`` exceeds ``max_pos`` is validated on the host BEFORE any launch.
         ``"raise"`` (default) fails the call; ``"drop"`` generates the other rows and reports the row in ``dropped`` (its
         tokens are pad, its logits NaN) — the reference runs batch 1, where one over-long prompt costs one utterance
-        (inference/inference.py:370-373), not the batch it happens to be collated with."""
+        (inference/inference.py:370-373), not the batch it happens to be collated with.
+
+        ``num_beams > 1``: HF beam search (``early_stopping=False``; ``length_penalty`` as in HF; see ``_generate_beam``)."""
         c, ws, dev = self.lm_cfg, self.ws, self.device
         if overlong not in ("raise", "drop"):
             raise ValueError(f"overlong must be 'raise' or 'drop', not {overlong!r}")
@@ -156,7 +159,8 @@ class CausalLMRuntimeMixin:
                                 suppress_eos=suppress_eos, want_first_logits=want_first_logits,
                                 cache_len_multiple=cache_len_multiple, do_sample=do_sample, temperature=temperature, top_p=top_p,
                                 top_k=top_k, repetition_penalty=repetition_penalty, generator=generator,
-                                sample_debug=sample_debug, want_step_logits=want_step_logits)
+                                sample_debug=sample_debug, want_step_logits=want_step_logits, num_beams=num_beams,
+                                length_penalty=length_penalty)
             n, kidx = len(plens), torch.tensor(keep)
             toks = torch.full((n, sub.tokens.shape[1]), c.pad_id if pad_id is None else pad_id, dtype=torch.int64)
             toks[kidx] = sub.tokens
@@ -173,6 +177,13 @@ class CausalLMRuntimeMixin:
         if suppress_eos:
             eos = -1  # benchmark mode: exactly max_new_tokens per row
         assert max_new_tokens >= 1
+        if num_beams != 1:
+            if num_beams < 1:
+                raise ValueError(f"num_beams must be >= 1, not {num_beams}")
+            if do_sample or repetition_penalty != 1.0 or want_step_logits:
+                raise NotImplementedError("beam search runs without sampling, repetition penalty or a per-step logits trace")
+            return self._generate_beam(prompts, speech, max_new_tokens, eos, pad, num_beams, float(length_penalty),
+                                       want_first_logits, cache_len_multiple, debug=beam_debug)
         h, lens = self.embed_prompts(prompts, speech)
         Bn = len(lens)
         need = max(lens) + max_new_tokens
@@ -287,6 +298,95 @@ class CausalLMRuntimeMixin:
             width = int(first_eos.max())
         return GenerateResult(tokens=out[:, :width].contiguous(), first_logits=first,
                               step_logits=trace.clone() if trace is not None else None)
+
+
+    beam_rows = 256            # decode rows (sequences x beams) per pass of beam search: the widest decode tile
+
+    def _generate_beam(self, prompts, speech, max_new_tokens: int, eos: int, pad: int, K: int, length_penalty: float,
+                       want_first_logits: bool, cache_len_multiple: int, debug: Optional[dict] = None) -> GenerateResult:
+        """HF beam search with ``inputs_embeds`` only (models/custom_salmon.py:704-715; transformers `_beam_search`,
+        early_stopping=False).  The prompt is prefilled ONCE per row (HF prefills K copies), its K/V rows are copied to the
+        row's K beams, and every step is `icl_beam_step` (log-softmax, the 2K best continuations, running / finished
+        bookkeeping) -> copy of the generated K/V positions from each beam's parent (`icl_kv_copy_spans_bf16`: the prompt part
+        is identical across a row's beams, so HF's whole-cache reorder is a copy of <= max_new_tokens positions) -> one
+        decode step over rows x K sequences.  Nothing synchronises with the host until the final D2H of the best hypotheses;
+        rows whose search has ended keep stepping with their finished slots frozen (HF stops its loop instead: same result).
+        ``debug`` (tests; single pass only): receives per step the logits the step scored, and the running sequences / parents /
+        tokens it chose."""
+        c, ws, dev = self.lm_cfg, self.ws, self.device
+        n_rows = len(prompts)
+        per_pass = max(1, self.beam_rows // K)
+        if n_rows > per_pass:                                  # rows x beams beyond the decode tile: run the rows in groups
+            assert debug is None
+            parts = [self._generate_beam(prompts[i:i + per_pass], speech, max_new_tokens, eos, pad, K, length_penalty,
+                                         want_first_logits, cache_len_multiple) for i in range(0, n_rows, per_pass)]
+            width = max(p.tokens.shape[1] for p in parts)
+            toks = torch.full((n_rows, width), pad, dtype=torch.int64)
+            r = 0
+            for p in parts:
+                toks[r:r + p.tokens.shape[0], :p.tokens.shape[1]] = p.tokens
+                r += p.tokens.shape[0]
+            first = torch.cat([p.first_logits for p in parts]) if want_first_logits else None
+            return GenerateResult(tokens=toks, first_logits=first)
+        h, lens = self.embed_prompts(prompts, speech)
+        Bn, T = len(lens), max_new_tokens
+        BK = Bn * K
+        need = max(lens) + T
+        max_len = -(-need // cache_len_multiple) * cache_len_multiple
+        assert max_len <= c.max_pos, f"prompt + new tokens ({need}) exceeds max_pos {c.max_pos}"   # validated by generate()
+        whole = self._cache(BK + Bn, max_len)                  # beams' sequences first, then the rows the prompts prefill into
+        cache, pre = whole.rows(0, BK), whole.rows(BK, BK + Bn)
+        r0 = 0
+        for b0 in range(0, Bn, self.prefill_chunk):
+            b1 = min(Bn, b0 + self.prefill_chunk)
+            r1 = r0 + sum(lens[b0:b1])
+            self.llama.prefill(ws, h[r0:r1], lens[b0:b1], pre.rows(b0, b1))
+            r0 = r1
+        cu_last, acc = [], 0
+        for s in lens:
+            acc += s
+            cu_last.append(acc - 1)
+        last = ws.get("gen_last", (Bn, c.hidden), F32)
+        B.gather_rows(h, _i32(cu_last, dev), last)
+        logits = self.llama.logits(ws, last, name="gen_logits")
+        first = logits.clone() if want_first_logits else None
+        st = B.BeamState(ws.get, Bn, K, T, pad)
+
+        def score(lg, step):
+            B.beam_step(lg, st, step, eos, length_penalty, V=c.vocab)
+            if debug is not None:
+                for key, val in (("logits", lg), ("run_seq", st.run_seq), ("parent", st.parent), ("next", st.next_ids),
+                                 ("fin_seq", st.fin_seq), ("fin_score", st.fin_score), ("fin_len", st.fin_len)):
+                    debug.setdefault(key, []).append(val.clone())
+        score(logits, 0)
+        lens_rep = [s for s in lens for _ in range(K)]
+        plen = ws.get("gen_beam_plen", (BK,), I32)
+        plen.copy_(torch.tensor(lens_rep, dtype=I32), non_blocking=True)
+        if T > 1:
+            src = ws.get("gen_beam_src", (BK,), I32)           # beam b*K+k starts from the prompt rows of sequence BK + b
+            src.copy_(torch.tensor([BK + b for b in range(Bn) for _ in range(K)], dtype=I32), non_blocking=True)
+            for kv in (whole.k, whole.v):
+                B.kv_copy_spans(kv, kv, BK, src_seq=src, n_t=plen)
+            steps = T - 1
+            pos_all = ws.get("gen_pos", (steps, BK), I32)
+            len_all = ws.get("gen_len", (steps, BK), I32)
+            sid = ws.get("gen_sid", (BK,), I32)
+            pos_all.copy_(torch.tensor([[s + t for s in lens_rep] for t in range(steps)], dtype=I32), non_blocking=True)
+            len_all.copy_(torch.tensor([[s + t + 1 for s in lens_rep] for t in range(steps)], dtype=I32), non_blocking=True)
+            sid.copy_(torch.arange(BK, dtype=I32), non_blocking=True)
+            tmp_k = ws.get("gen_beam_tmp_k", (c.n_layers, BK, c.n_heads, steps, c.head_dim), BF16)
+            tmp_v = ws.get("gen_beam_tmp_v", tuple(tmp_k.shape), BF16)
+            for t in range(steps):
+                if t:                                          # the t positions generated so far follow their beam's parent
+                    for kv, tmp in ((cache.k, tmp_k), (cache.v, tmp_v)):
+                        B.kv_copy_spans(kv, tmp, BK, src_seq=st.parent, src_t0=plen, n_fixed=t)
+                        B.kv_copy_spans(tmp, kv, BK, dst_t0=plen, n_fixed=t)
+                lg = self.llama.decode_step(ws, cache, st.next_ids, pos_all[t], len_all[t], sid)
+                score(lg, t + 1)
+        best = st.fin_seq[:, 0].cpu().to(torch.int64)                                   # the only D2H pair of the call
+        blen = st.fin_len[:, 0].cpu()
+        width = max(1, int(blen.max()))
+        return GenerateResult(tokens=best[:, :width].contiguous(), first_logits=first)
 
 
 class SalmonnRuntime(CausalLMRuntimeMixin):

@@ -324,6 +324,33 @@ int icl_beats_posconv_pack(float* x, const int32_t* cu_rows, const int32_t* vali
 int icl_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, float* out, int64_t ld_out,
                         int32_t rows, int32_t N, void* stream);
 
+/* ---- K11 (beam search): one step of HF's static-shaped beam search + the cache reorder ------------------------------
+ * icl_beam_step, per batch row b (num_beams K <= 8, max_new_tokens T <= 64, V >= 2K): log-softmax of the K beams' logits
+ *   (row b*rows_per_batch + k; rows_per_batch == 1 at step 0, where the K beams still share the prompt's one distribution) plus
+ *   run_score[b][k]; the 2K best continuations (ties: lower beam*V + token); a continuation stops when its token is eos_id
+ *   or step + 1 == T.  run_* <- the K best that do not stop (score - 1e9 if only stopping ones are left); fin_* <- the K best of
+ *   {old finished slots, first-K continuations that stop, scored sum / (step+1)**length_penalty}, taken only while unsat[b];
+ *   unsat[b] &= (run_score[b][0] / (step+1)**length_penalty beats the worst finished slot, or a slot is still empty).
+ *   next_ids[b*K+i] / parent[b*K+i] = token and absolute source row (b*K + parent beam) of running beam i.
+ *   Initial state: run_score = {0, -1e9, ...}, fin_score = -1e9, fin_flag = fin_len = 0, unsat = 1, sequences = pad.
+ *   The answer after T steps is fin_seq[b][0][0 .. fin_len[b][0]).
+ *   Replaces HF GenerationMixin._beam_search (early_stopping=False, do_sample=False) behind generate(inputs_embeds=...,
+ *   num_beams, length_penalty) at models/custom_salmon.py:704-715 (per-task values: models/multi_task_model.py:142).
+ * icl_kv_copy_spans_bf16: for every layer l < n_layers, head h < n_heads and row r < n_rows, copy n (= n_t[r], or n_fixed when
+ *   n_t is NULL) positions of head_dim bf16 from src[l][src_seq[r]][h][src_t0[r] ..] to dst[l][dst_seq[r]][h][dst_t0[r] ..]
+ *   (NULL seq array = r, NULL t0 array = 0; strides in elements).  src and dst spans must not overlap.  Stands in for HF's
+ *   cache.reorder_cache(beam_idx): only the positions after the prompt differ between the beams of a row.
+ */
+int icl_beam_step(const float* logits, int64_t ldl, int32_t rows_per_batch, int32_t B, int32_t V, int32_t num_beams,
+                  int32_t max_new_tokens, int32_t step, int32_t eos_id, float length_penalty, float* run_score,
+                  int32_t* run_seq, float* fin_score, int32_t* fin_seq, int32_t* fin_len, int32_t* fin_flag,
+                  int32_t* unsat, int32_t* next_ids, int32_t* parent, void* stream);
+int icl_kv_copy_spans_bf16(const void* src, void* dst, int64_t src_layer_stride, int64_t src_seq_stride,
+                           int64_t src_head_stride, int64_t dst_layer_stride, int64_t dst_seq_stride,
+                           int64_t dst_head_stride, const int32_t* src_seq, const int32_t* src_t0,
+                           const int32_t* dst_seq, const int32_t* dst_t0, const int32_t* n_t, int32_t n_fixed,
+                           int32_t n_rows, int32_t n_layers, int32_t n_heads, int32_t head_dim, void* stream);
+
 /* ---- K12: causal-LM cross entropy (teacher-forced forward only) -------------------------------
  * row_loss[r] = logsumexp(logits[r][:]) - logits[r][labels[r]] for labels[r] in [0,V), else 0;
  * mean_loss[0] = mean of row_loss over the valid rows (NaN if none) — torch CrossEntropyLoss with

@@ -420,76 +420,24 @@ class LlamaOracle:
 
     def generate_beam(self, inputs_embeds: Tensor, max_new_tokens: int, eos_id: int, pad_id: int, num_beams: int,
                       length_penalty: float = 1.0, return_scores: bool = False):
-        """HF beam search (transformers/generation/utils.py `_beam_search`, early_stopping=False, one EOS id, do_sample=False)
-        as ``generate(inputs_embeds=..., num_beams=K, length_penalty=...)`` runs it for models/custom_salmon.py:704-715 /
-        models/multi_task_model.py:142: the prompt length is 0 for the scorer (only new tokens are counted), 2K continuations
-        are kept per row and step, the K best of them that do not stop run on, those among the first K that stop (EOS or the
-        length limit) compete for the K finished slots with score = sum of log-probs / len**length_penalty, and a row stops
-        taking finished hypotheses once its best running score / cur_len**length_penalty no longer beats its worst finished
-        one.  Returns the best finished hypothesis per row [B, width] padded with ``pad_id`` (width = longest returned)."""
+        """HF beam search as ``generate(inputs_embeds=..., num_beams=K, length_penalty=...)`` runs it for
+        models/custom_salmon.py:704-715 / models/multi_task_model.py:142 (bookkeeping: ``BeamBookkeeping``).  Returns the best
+        finished hypothesis per row [B, width] padded with ``pad_id`` (width = longest returned)."""
         Bn, T, _ = inputs_embeds.shape
-        K, V = num_beams, None
-        NEG = torch.tensor(-1.0e9, dtype=torch.float32)
+        K = num_beams
         cache: list = []
         h = self.forward_hidden(inputs_embeds.float(), torch.arange(T)[None].expand(Bn, T), cache)
         lg = self.logits(h[:, -1:])[:, 0]                                             # [B, V]
         cache = [(k.repeat_interleave(K, 0), v.repeat_interleave(K, 0)) for k, v in cache]
         lg = lg.repeat_interleave(K, 0)                                               # beam-major rows: b * K + k
-        V = lg.shape[-1]
-        run_seq = [[[] for _ in range(K)] for _ in range(Bn)]
-        run_score = torch.full((Bn, K), -1.0e9, dtype=torch.float32)
-        run_score[:, 0] = 0.0
-        fin = [[(NEG.clone(), [], False) for _ in range(K)] for _ in range(Bn)]        # (score, tokens, finished)
-        unsat = [True] * Bn
+        bk = BeamBookkeeping(Bn, K, max_new_tokens, eos_id, length_penalty)
         for step in range(max_new_tokens):
-            logp = F.log_softmax(lg.float(), dim=-1).view(Bn, K, V)
-            acc = (logp + run_score[:, :, None]).view(Bn, K * V)
-            top_v, top_i = torch.topk(acc, 2 * K, dim=1)
-            parents = torch.zeros(Bn, K, dtype=torch.long)
-            toks = torch.zeros(Bn, K, dtype=torch.long)
-            all_stop = True
-            for b in range(Bn):
-                cand = []
-                for j in range(2 * K):
-                    par, tok = int(top_i[b, j]) // V, int(top_i[b, j]) % V
-                    stops = (tok == eos_id) or (step + 1 >= max_new_tokens)
-                    cand.append((top_v[b, j], par, tok, stops, run_seq[b][par] + [tok]))
-                all_stop = all_stop and all(c[3] for c in cand)
-                # the K best continuations that do not stop run on (a stopping one keeps its place in line at score - 1e9)
-                order = sorted(range(2 * K), key=lambda j: (-float(cand[j][0] + (NEG if cand[j][3] else 0.0)), j))[:K]
-                # finished slots: only the first K continuations may finish, and only while the row can still improve
-                lenpen = float(step + 1) ** length_penalty
-                merged = list(fin[b])
-                for j, (v, par, tok, stops, seq) in enumerate(cand):
-                    sc = v / lenpen
-                    if not unsat[b]:
-                        sc = sc + NEG
-                    just = stops and j < K
-                    if not just:
-                        sc = sc + NEG
-                    merged.append((sc, seq, just))
-                keep = sorted(range(len(merged)), key=lambda j: (-float(merged[j][0]), j))[:K]
-                fin[b] = [merged[j] for j in keep]
-                new_seq = [cand[j][4] for j in order]
-                for i, j in enumerate(order):
-                    run_score[b, i] = cand[j][0] + (NEG if cand[j][3] else 0.0)
-                    parents[b, i], toks[b, i] = cand[j][1], cand[j][2]
-                run_seq[b] = new_seq
-                # can the best running beam still beat the worst finished hypothesis of this row?
-                best = run_score[b, 0] / (float(step + 1) ** length_penalty)
-                worst = min(f[0] for f in fin[b])
-                unsat[b] = unsat[b] and any(bool(best > (worst if f[2] else NEG)) for f in fin[b])
-            if not any(unsat) or all_stop:
+            parents, toks = bk.step(lg)
+            if bk.done:
                 break
-            flat_par = (parents + torch.arange(Bn)[:, None] * K).reshape(-1)
-            cache = [(k[flat_par], v[flat_par]) for k, v in cache]
-            e = self.embed(toks.reshape(-1))[:, None]
-            lg = self.logits(self.forward_hidden(e, torch.full((Bn * K, 1), T + step), cache))[:, 0]
-        width = max(len(fin[b][0][1]) for b in range(Bn))
-        out = torch.full((Bn, width), pad_id, dtype=torch.long)
-        for b in range(Bn):
-            out[b, : len(fin[b][0][1])] = torch.tensor(fin[b][0][1], dtype=torch.long)
-        scores = torch.stack([fin[b][0][0] for b in range(Bn)])
+            cache = [(k[parents], v[parents]) for k, v in cache]
+            lg = self.logits(self.forward_hidden(self.embed(toks)[:, None], torch.full((Bn * K, 1), T + step), cache))[:, 0]
+        out, scores = bk.result(pad_id)
         return (out, scores) if return_scores else out
 
     def teacher_forced_logits(self, inputs_embeds: Tensor, tokens: Tensor) -> Tensor:
@@ -539,6 +487,77 @@ class LlamaOracle:
                 break
             lg = self.logits(self.forward_hidden(self.embed(tok)[:, None], torch.full((B, 1), T + step), cache))[:, 0]
         return torch.stack(out, dim=1), kept
+
+
+class BeamBookkeeping:
+    """The scorer of HF beam search (transformers/generation/utils.py `_beam_search`, early_stopping=False, one EOS id,
+    do_sample=False, prompt length 0 as with inputs_embeds), one ``step(logits [B*K, V])`` at a time:
+      * 2K continuations are kept per row (best accumulated log-probability first);
+      * the K best of them that do not stop (EOS or the length limit) run on — a stopping one stays in line at score - 1e9;
+      * those among the first K that stop compete for the K finished slots at sum / len**length_penalty, but only while the
+        row is open; the row closes once its best running score / cur_len**length_penalty no longer beats its worst
+        finished slot (all K slots filled);
+      * the search ends when every row is closed or every continuation stopped (length limit)."""
+
+    def __init__(self, Bn: int, K: int, max_new_tokens: int, eos_id: int, length_penalty: float):
+        self.Bn, self.K, self.T, self.eos, self.lp = Bn, K, max_new_tokens, eos_id, length_penalty
+        self.neg = torch.tensor(-1.0e9, dtype=torch.float32)
+        self.run_seq = [[[] for _ in range(K)] for _ in range(Bn)]
+        self.run_score = torch.full((Bn, K), -1.0e9, dtype=torch.float32)
+        self.run_score[:, 0] = 0.0
+        self.fin = [[(self.neg.clone(), [], False) for _ in range(K)] for _ in range(Bn)]      # (score, tokens, finished)
+        self.open = [True] * Bn
+        self.t = 0
+        self.done = False
+
+    def step(self, lg: Tensor):
+        """-> (parent row index b*K + k, token) per running beam [B*K] for the next forward pass."""
+        Bn, K, NEG, step = self.Bn, self.K, self.neg, self.t
+        V = lg.shape[-1]
+        logp = F.log_softmax(lg.float(), dim=-1).view(Bn, K, V)
+        acc = (logp + self.run_score[:, :, None]).view(Bn, K * V)
+        top_v, top_i = torch.sort(acc, dim=1, descending=True, stable=True)      # torch.topk, with ties to the lower beam*V + token
+        top_v, top_i = top_v[:, : 2 * K], top_i[:, : 2 * K]
+        parents = torch.zeros(Bn, K, dtype=torch.long)
+        toks = torch.zeros(Bn, K, dtype=torch.long)
+        lenpen = float(step + 1) ** self.lp
+        all_stop = True
+        for b in range(Bn):
+            cand = []
+            for j in range(2 * K):
+                par, tok = int(top_i[b, j]) // V, int(top_i[b, j]) % V
+                stops = (tok == self.eos) or (step + 1 >= self.T)
+                cand.append((top_v[b, j], par, tok, stops, self.run_seq[b][par] + [tok]))
+            all_stop = all_stop and all(c[3] for c in cand)
+            order = sorted(range(2 * K), key=lambda j: (-float(cand[j][0] + (NEG if cand[j][3] else 0.0)), j))[:K]
+            merged = list(self.fin[b])
+            for j, (v, par, tok, stops, seq) in enumerate(cand):
+                sc = v / lenpen
+                if not self.open[b]:
+                    sc = sc + NEG
+                just = stops and j < K
+                if not just:
+                    sc = sc + NEG
+                merged.append((sc, seq, just))
+            keep = sorted(range(len(merged)), key=lambda j: (-float(merged[j][0]), j))[:K]
+            self.fin[b] = [merged[j] for j in keep]
+            self.run_seq[b] = [cand[j][4] for j in order]
+            for i, j in enumerate(order):
+                self.run_score[b, i] = cand[j][0] + (NEG if cand[j][3] else 0.0)
+                parents[b, i], toks[b, i] = cand[j][1], cand[j][2]
+            best = self.run_score[b, 0] / lenpen
+            worst = min(f[0] for f in self.fin[b])
+            self.open[b] = self.open[b] and any(bool(best > (worst if f[2] else NEG)) for f in self.fin[b])
+        self.t += 1
+        self.done = self.done or not any(self.open) or all_stop
+        return (parents + torch.arange(Bn)[:, None] * K).reshape(-1), toks.reshape(-1)
+
+    def result(self, pad_id: int):
+        width = max(len(self.fin[b][0][1]) for b in range(self.Bn))
+        out = torch.full((self.Bn, width), pad_id, dtype=torch.long)
+        for b in range(self.Bn):
+            out[b, : len(self.fin[b][0][1])] = torch.tensor(self.fin[b][0][1], dtype=torch.long)
+        return out, torch.stack([self.fin[b][0][0] for b in range(self.Bn)])
 
 
 def sample_filter(logits, prev_tokens, repetition_penalty: float, temperature: float, top_k: int, top_p: float):

@@ -866,3 +866,97 @@ def test_sample_eos_matches_oracle_and_hf_golden():
     toks, nxt, fin, _ = _sample_case(logits, torch.zeros(2, 16, dtype=torch.long), 0, 1.0, 1, 1.0, 1.0, torch.zeros(2),
                                      eos=top, pad=7, finished=torch.tensor([1, 0]))
     assert nxt.tolist() == [7, top] and fin.tolist() == [1, 1]
+
+
+# ---- beam search: the step kernel against the oracle's scorer, the span copy against indexing -----------------------------------
+@pytest.mark.parametrize("Bn,K,V,T,lp,eos", [(3, 4, 260, 6, 1.0, 17), (2, 8, 32001, 5, 2.0, 2), (5, 1, 40, 4, 0.0, 3),
+                                              (2, 3, 1000, 64, -1.0, 5), (1, 2, 4, 3, 1.0, 0)])
+def test_beam_step_matches_oracle_scorer(B, Bn, K, V, T, lp, eos):
+    """A whole search on synthetic logits that depend on each beam's history (a tiny recurrent stand-in for the decoder, advanced
+    along the chosen parents): `icl_beam_step` and oracle.BeamBookkeeping must choose the same parents / tokens at every step and
+    return the same hypotheses; peaked columns make EOS and a few exact ties (lower beam*V + token wins) part of the race."""
+    from oracle import models as om
+    g = torch.Generator().manual_seed(Bn * 1000 + K * 10 + T)
+    Hd = 12
+    A = torch.randn(Hd, Hd, generator=g) * 0.6
+    E = torch.randn(V, Hd, generator=g)
+    U = torch.randn(Hd, V, generator=g) * 1.5
+    U[:, eos] += 0.8                                    # EOS is a frequent contender
+    h = torch.randn(Bn, Hd, generator=g)
+    state = B.BeamState(lambda name, shape, dt: torch.empty(shape, dtype=dt, device=DEV), Bn, K, T, pad_id=V - 1)
+    bk = om.BeamBookkeeping(Bn, K, T, eos, lp)
+
+    def logits_of(hid):
+        lg = (hid @ U).float()
+        if V > 20:
+            lg[:, 7] = lg[:, 11]                        # an exact tie between two tokens of every beam
+        return lg.contiguous()
+    hid = h
+    lg = logits_of(hid)                                 # step 0: one distribution per row
+    for s in range(T):
+        B.beam_step(lg.to(DEV), state, s, eos, lp)
+        lg_bk = lg if lg.shape[0] == Bn * K else lg.repeat_interleave(K, 0)
+        was_open = list(bk.open)
+        parents, toks = bk.step(lg_bk)
+        gp, gt = state.parent.cpu().long(), state.next_ids.cpu().long()
+        if s + 1 < T:
+            assert torch.equal(gt, toks) and torch.equal(gp, parents), (s, gt, toks, gp, parents)
+        fin_s = torch.stack([torch.stack([f[0] for f in bk.fin[b]]) for b in range(Bn)])
+        assert torch.allclose(state.fin_score.cpu(), fin_s, rtol=2e-6, atol=1e-6), (s, state.fin_score.cpu(), fin_s)
+        assert state.unsat.cpu().tolist() == [int(o) for o in bk.open], (s, was_open)
+        for b in range(Bn):
+            for k in range(K):
+                if bk.fin[b][k][2]:
+                    n = len(bk.fin[b][k][1])
+                    assert int(state.fin_len[b, k]) == n and state.fin_seq[b, k, :n].cpu().tolist() == bk.fin[b][k][1]
+        if s + 1 == T:
+            break
+        hid_rows = hid if hid.shape[0] == Bn * K else hid.repeat_interleave(K, 0)
+        hid = torch.tanh(hid_rows[parents] @ A + E[toks])
+        lg = logits_of(hid)
+    want, score = bk.result(V - 1)
+    n = state.fin_len[:, 0].cpu()
+    for b in range(Bn):
+        assert state.fin_seq[b, 0, :int(n[b])].cpu().tolist() == [t for t in want[b].tolist()][:int(n[b])]
+    assert torch.allclose(state.fin_score[:, 0].cpu(), score, rtol=2e-6, atol=1e-6)
+
+
+def test_beam_step_rejects_bad_arguments(B):
+    st = B.BeamState(lambda name, shape, dt: torch.empty(shape, dtype=dt, device=DEV), 2, 2, 4, pad_id=0)
+    lg = torch.zeros(2, 3, device=DEV)
+    with pytest.raises(B.IclError):
+        B.beam_step(lg, st, 0, 1, 1.0)                  # V < 2 * num_beams
+    with pytest.raises(B.IclError):
+        B.beam_step(torch.zeros(2, 50, device=DEV), st, 4, 1, 1.0)      # step outside [0, T)
+    st9 = B.BeamState(lambda name, shape, dt: torch.empty(shape, dtype=dt, device=DEV), 1, 9, 4, pad_id=0)
+    with pytest.raises(B.IclError):
+        B.beam_step(torch.zeros(1, 50, device=DEV), st9, 0, 1, 1.0)     # more than 8 beams
+
+
+def test_kv_copy_spans(B):
+    """Prompt rows to the beams of a row (ragged lengths), then generated positions from each beam's parent via a staging buffer."""
+    L, S, H, P, D = 3, 8, 2, 24, 64
+    cache = torch.randn(L, S, H, P, D, device=DEV).to(torch.bfloat16)
+    ref = cache.clone()
+    view, rview = cache[:, :6], ref[:, :6]             # six beam sequences + two prompt rows: a view with the parent's strides
+    src = torch.tensor([6, 6, 6, 7, 7, 7], dtype=torch.int32, device=DEV)
+    n_t = torch.tensor([5, 5, 5, 9, 9, 0], dtype=torch.int32, device=DEV)
+    B.kv_copy_spans(cache, cache, 6, src_seq=src, n_t=n_t)
+    for r in range(6):
+        n = int(n_t[r])
+        ref[:, r, :, :n] = ref[:, int(src[r]), :, :n]
+    assert torch.equal(cache, ref)
+    parent = torch.tensor([1, 0, 0, 5, 3, 4], dtype=torch.int32, device=DEV)
+    t0 = torch.tensor([5, 5, 5, 9, 9, 9], dtype=torch.int32, device=DEV)
+    tmp = torch.zeros(L, 6, H, 4, D, dtype=torch.bfloat16, device=DEV)
+    B.kv_copy_spans(view, tmp, 6, src_seq=parent, src_t0=t0, n_fixed=3)
+    B.kv_copy_spans(tmp, view, 6, dst_t0=t0, n_fixed=3)
+    want = rview.clone()
+    for r in range(6):
+        a = int(t0[r])
+        want[:, r, :, a:a + 3] = rview[:, int(parent[r]), :, a:a + 3]
+    assert torch.equal(view, want) and torch.equal(cache[:, 6:], ref[:, 6:])
+    assert torch.equal(tmp[:, :, :, 3], torch.zeros_like(tmp[:, :, :, 3]))
+    B.kv_copy_spans(view, tmp, 6, n_fixed=0)           # nothing to copy: no launch, no error
+    with pytest.raises(B.IclError):
+        B.kv_copy_spans(cache.cpu(), tmp, 6, n_fixed=1)

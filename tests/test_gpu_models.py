@@ -389,3 +389,99 @@ def test_workspace_stays_bounded_over_ragged_batches(env):
     again = rt.generate(probe, None, max_new_tokens=6, suppress_eos=True, want_first_logits=True)
     assert torch.equal(again.tokens, want_tok) and torch.equal(again.first_logits, want_first)
     assert torch.equal(rt.encode_speech(probe_wav, [30000, 47000]), want_emb)
+
+
+def _beam_replay(dbg, Bn, K, T, eos, lp, pad):
+    """The oracle's scorer driven by the logits the GPU search itself scored, step by step."""
+    from oracle import models as om
+    bk = om.BeamBookkeeping(Bn, K, T, eos, lp)
+    steps = []
+    for s, lg in enumerate(dbg["logits"]):
+        lg = lg.cpu()
+        if lg.shape[0] == Bn:
+            lg = lg.repeat_interleave(K, 0)
+        parents, toks = bk.step(lg)
+        steps.append((parents, toks))
+        if bk.done:
+            break
+    return bk, steps
+
+
+@pytest.mark.parametrize("K,lp,eos_from", [(3, 1.0, None), (4, 1.0, (0, 2)), (2, 0.0, (1, 1)), (4, 2.0, (2, 3)), (3, -1.0, (0, 1)),
+                                           (1, 1.0, None)])
+def test_beam_search_matches_oracle(env, K, lp, eos_from):
+    """num_beams > 1 (models/custom_salmon.py:709-714 -> HF _beam_search).  Three checks on ragged prompts:
+    (1) the oracle's scorer replayed on the logits the GPU search scored reproduces the GPU's choices at every step (parents,
+        tokens) and its answer — the device bookkeeping is HF's;
+    (2) those logits are the model's: every running beam's logits equal the bf16-rounding oracle teacher-forced along that beam's
+        history (prompt K/V copied to the beams, generated positions following the parent, decode over rows x K sequences);
+    (3) the free-running oracle finds the same hypothesis wherever no decision inside the 2K window was closer than the logit error."""
+    from oracle import models as om
+    cfg, sd, rt = env
+    lens = [33, 90, 12]
+    T = 6
+    prompts = _prompts(cfg, lens, seed=17)
+    pad = cfg.llama.pad_id
+    eos = -1
+    if eos_from is not None:            # an EOS some hypothesis meets: the token the unconstrained search puts at (row, step)
+        free = rt.generate(prompts, None, max_new_tokens=T, suppress_eos=True, num_beams=K, length_penalty=lp)
+        eos = int(free.tokens[eos_from[0], eos_from[1]])
+    dbg = {}
+    if K == 1:                          # generate() sends one beam down the greedy path; the beam machinery must agree with it
+        res = rt._generate_beam(prompts, None, T, eos, pad, 1, lp, True, 64, debug=dbg)
+    else:
+        res = rt.generate(prompts, None, max_new_tokens=T, eos_id=eos, pad_id=pad, num_beams=K, length_penalty=lp,
+                          want_first_logits=True, beam_debug=dbg, suppress_eos=eos < 0)
+    Bn = len(lens)
+    assert len(dbg["logits"]) == T and dbg["logits"][0].shape[0] == Bn and dbg["logits"][1].shape[0] == Bn * K
+    # (1) bookkeeping replay
+    bk, steps = _beam_replay(dbg, Bn, K, T, eos, lp, pad)
+    for s, (parents, toks) in enumerate(steps):
+        got_par, got_tok = dbg["parent"][s].cpu().long(), dbg["next"][s].cpu().long()
+        if s + 1 < T:                           # at the length limit every continuation stops: the running order is arbitrary
+            assert torch.equal(got_tok, toks) and torch.equal(got_par, parents), (s, got_tok, toks, got_par, parents)
+    want, want_score = bk.result(pad)
+    assert res.tokens.tolist() == want.tolist(), (res.tokens, want)
+    got_score = dbg["fin_score"][-1][:, 0].cpu()
+    assert torch.allclose(got_score, want_score, rtol=1e-5, atol=1e-5), (got_score, want_score)
+    # (2) the logits of every running beam, against the oracle teacher-forced along that beam's tokens
+    ob = _llama_oracle(cfg, sd, om.bf16_round)
+    worst = 0.0
+    for b, segs in enumerate(prompts):
+        emb = ob.embed(torch.tensor(segs[0]))[None]
+        for s in range(1, T):
+            hist = dbg["run_seq"][s - 1][b].cpu().long()[:, :s]          # [K, s]: the tokens fed so far
+            for k in range(K):
+                tf = ob.teacher_forced_logits(emb, torch.cat([hist[k], torch.zeros(1, dtype=torch.long)])[None])[0, s]
+                g = dbg["logits"][s][b * K + k].cpu()
+                worst = max(worst, float((g - tf).norm() / tf.norm()))
+    print(f"beam K={K} lp={lp} eos={eos}: step-logit rel-L2 max over beams {worst:.2e}; answer {res.tokens.tolist()}")
+    assert worst < TOL_LOGITS_REL
+    # (3) free-running oracle (informative: a near-tie inside the 2K window may legitimately differ)
+    embs = [ob.embed(torch.tensor(p[0]))[None] for p in prompts]
+    same = 0
+    for b, e in enumerate(embs):
+        ids = ob.generate_beam(e, T, eos, pad, K, lp)[0].tolist()
+        g = res.tokens[b].tolist()
+        g = g[:len(ids)] if all(t == pad for t in g[len(ids):]) else g
+        same += int(g == ids)
+    print(f"free-running oracle agrees on {same}/{Bn} rows")
+    if K == 1:      # one beam is greedy search (HF's own equivalence): the GPU's greedy path must give the same ids
+        greedy = rt.generate(prompts, None, max_new_tokens=T, eos_id=eos, pad_id=pad, suppress_eos=eos < 0)
+        assert greedy.tokens.tolist() == res.tokens.tolist()
+
+
+def test_beam_search_in_row_groups_matches_one_pass(env):
+    """rows x beams above the decode tile run in groups of rows: same answers as one pass."""
+    cfg, sd, rt = env
+    prompts = _prompts(cfg, [20, 41, 33, 17, 25], seed=23)
+    one = rt.generate(prompts, None, max_new_tokens=5, suppress_eos=True, num_beams=3)
+    old = rt.beam_rows
+    try:
+        rt.beam_rows = 6            # two rows per pass
+        grouped = rt.generate(prompts, None, max_new_tokens=5, suppress_eos=True, num_beams=3, want_first_logits=True)
+    finally:
+        rt.beam_rows = old
+    assert grouped.tokens.tolist() == one.tokens.tolist() and grouped.first_logits.shape[0] == 5
+    with pytest.raises(NotImplementedError):
+        rt.generate(prompts, None, max_new_tokens=5, num_beams=3, do_sample=True)
