@@ -69,6 +69,39 @@ def test_one_overlong_row_costs_its_own_utterance_only(model):
     assert len(model.generate_output(dict(b))) == 4                  # and the model is usable afterwards
 
 
+def test_beam_search_through_the_plugins(model):
+    """`num_beams` / `length_penalty` in the batch dict (models/custom_salmon.py:709-714) and in a task's config
+    (models/multi_task_model.py:142) reach the beam kernels; the plugin's answer is the runtime's and the oracle's."""
+    from oracle import models as om
+    from icl_speech_text_llm_amd.models.model_factory import ModelFactory
+    b = _batch(model, "text", n=2, bs=2)
+    b = {k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    greedy = model.generate_ids(dict(b))
+    beams = model.generate_ids(dict(b, num_beams=3, length_penalty=1.0, max_new_tokens=6), want_first_logits=True)
+    assert beams.tokens.shape[0] == 2 and beams.tokens.shape[1] <= 6 and torch.equal(beams.first_logits.argmax(-1).cpu(), greedy.tokens[:, 0])
+    texts = model.generate_output(dict(b, num_beams=3, max_new_tokens=6))
+    assert texts == model.decode_ids(beams.tokens)
+    # oracle on the same embeddings: the reference's dense wrap (equal lengths are not needed at batch 1)
+    llm = _oracle_llama(model, om.bf16_round)
+    speech, _, _, _ = model.get_speech_embeddings(dict(b))          # batched, as generate_ids sees them
+    for i in range(2):
+        emb, _ = model.custom_prompt_wrap(speech[i:i + 1], None, b["prompt"][i:i + 1], b["num_examples"][i:i + 1].cpu(), None)
+        ids = llm.generate_beam(emb.float().cpu(), 6, model.llama_tokenizer.eos_token_id, model.llama_tokenizer.pad_token_id, 3, 1.0)
+        got = beams.tokens[i].tolist()
+        print(f"plugin beams row {i}: gpu {got} oracle {ids[0].tolist()}")
+        assert got[: ids.shape[1]] == ids[0].tolist()
+    with pytest.raises(NotImplementedError):
+        model.generate_ids(dict(b, num_beams=2, do_sample=True))
+    tasks = {"beamed": {"max_new_tokens": 4, "num_beams": 2}}
+    m = ModelFactory.create_model("salmonn", multi_task=True, task_configs=tasks, default_task="beamed", device="cuda",
+                                  arch="tiny", llama_path="none").eval()
+    bb = dict(_batch(m.model, "text", n=2, bs=2))
+    bb = {k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in bb.items()}
+    bb["task"] = ["beamed", "beamed"]
+    out = m.generate_output(bb)
+    assert bb["num_beams"] == 2 and len(out) == 2
+
+
 def test_get_speech_embeddings_matches_oracle_batch1(model):
     from oracle import audio_frontend as af, models as om
     b = _batch(model, "speech", n=1, bs=1, num_examples=2, vary=True)

@@ -88,6 +88,11 @@ def test_forward_and_generate_match_oracle(model):
     print(f"qwen first-step logits max abs {e:.2e}")
     assert e < 5e-3                      # measured 2.1e-3
     assert res.tokens.shape == (1, 5)
+    # beam search through the plugin's batch keys (generation_config knobs; transformers _beam_search rules)
+    beams = model.generate_ids(dict(gen_batch, num_beams=3, length_penalty=1.0, max_new_tokens=4))
+    want = llm.generate_beam(emb[None, :prompt_len], 4, c.eos_id, c.pad_id, 3, 1.0)
+    print(f"qwen beams: gpu {beams.tokens.tolist()} oracle {want.tolist()}")
+    assert beams.tokens[0, : want.shape[1]].tolist() == want[0].tolist()
 
 
 def test_padded_batch_rows_are_packed(model):
