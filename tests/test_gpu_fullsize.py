@@ -74,6 +74,32 @@ def test_generate_is_deterministic_and_full_width(rt):
     assert int(r1.min()) >= 0 and int(r1.max()) < 32001
 
 
+def test_beam_search_at_full_size_is_consistent(rt):
+    """Llama-2-7B dims (32 layers x 32 heads x 128): one beam through the beam machinery (prompt K/V copied to the beam rows,
+    decode over them, device bookkeeping) gives the greedy ids; four beams in one pass and in row groups give the same answer,
+    deterministically, and the best hypothesis starts from one of the prompt's four most likely tokens."""
+    from icl_speech_text_llm_amd.runtime.salmonn import speech_segment
+    speech = torch.randn(3, 88, 4096, device="cuda") * 0.02
+    p = [[_ids(5, 280), speech_segment(0, 88), _ids(6, 8)], [_ids(7, 120), speech_segment(88, 88)], [_ids(8, 40), speech_segment(176, 88), _ids(9, 33)],
+         [_ids(10, 64)], [_ids(11, 150), speech_segment(0, 88)], [_ids(12, 90)]]
+    greedy = rt.generate(p, speech, max_new_tokens=6, suppress_eos=True, want_first_logits=True)
+    one = rt._generate_beam(p, speech, 6, -1, rt.lm_cfg.pad_id, 1, 1.0, False, 64)
+    assert torch.equal(one.tokens, greedy.tokens)
+    b4 = rt.generate(p, speech, max_new_tokens=6, suppress_eos=True, num_beams=4)
+    again = rt.generate(p, speech, max_new_tokens=6, suppress_eos=True, num_beams=4)
+    assert b4.tokens.shape == (6, 6) and torch.equal(b4.tokens, again.tokens)
+    old = rt.beam_rows
+    try:
+        rt.beam_rows = 12                # three rows per pass: 12 and 24 decode rows both run the decode tile, whose arithmetic per
+                                         # row does not depend on the row count (the <= 8-row skinny kernel sums in another order)
+        grouped = rt.generate(p, speech, max_new_tokens=6, suppress_eos=True, num_beams=4)
+    finally:
+        rt.beam_rows = old
+    assert torch.equal(grouped.tokens, b4.tokens)
+    top4 = greedy.first_logits.topk(4, dim=-1).indices.cpu()
+    assert all(int(b4.tokens[i, 0]) in top4[i].tolist() for i in range(6))
+
+
 def test_logmel_of_silence_is_the_closed_form_constant(rt):
     # all-zero audio: power 0 -> log10(1e-10) = -10 everywhere -> max-8 clamp keeps -10 -> (x+4)/4 = -1.5
     spec = rt.log_mel(torch.zeros(1, 480000), [480000])
