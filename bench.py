@@ -539,7 +539,7 @@ def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batche
                            "times are bracketed by barriers, utt_per_s = all ranks' utterances / MAX over ranks of the wall time"}
 
 
-def quick_workload(wl: str, dev, batch: int = 64, steps: int = 3, warmup: int = 1):
+def quick_workload(wl: str, dev, batch: int = 64, steps: int = 3, warmup: int = 1, num_beams: int = 1):
     """One of the non-headline workloads of BASELINE.md §4, in THIS process (a process that has initialised the GPU must not
     start GPU children): build the seeded model, keep `warmup + steps` micro-batches resident, two untimed passes for the decode
     graph, then time `steps` passes.  Same step definition as the headline loop (encoders -> prefill -> 10 greedy tokens)."""
@@ -569,7 +569,7 @@ def quick_workload(wl: str, dev, batch: int = 64, steps: int = 3, warmup: int = 
 
     def step(s_):
         speech = rt.encode_audio(raw_wav=wavs[s_], wav_lens=lens)[0] if is_qwen else rt.encode_speech(wavs[s_], lens)
-        return rt.generate(prompts[s_], speech, max_new_tokens=NEW_TOKENS, suppress_eos=True).tokens
+        return rt.generate(prompts[s_], speech, max_new_tokens=NEW_TOKENS, suppress_eos=True, num_beams=num_beams).tokens
     for s_ in range(max(warmup, 2)):          # eager pass + capture pass of the decode graph, before the clock
         step(min(s_, warmup + steps - 1))
     torch.cuda.synchronize()
@@ -578,7 +578,7 @@ def quick_workload(wl: str, dev, batch: int = 64, steps: int = 3, warmup: int = 
         toks = step(s_)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = {"workload": wl_desc, "value": round(batch * steps / dt, 2), "unit": "utterances/s", "ms_per_step": round(dt / steps * 1e3, 1),
+    out = {"workload": wl_desc + (f", beam search with {num_beams} beams" if num_beams > 1 else ""), "value": round(batch * steps / dt, 2), "unit": "utterances/s", "ms_per_step": round(dt / steps * 1e3, 1),
            "utterances_per_step": batch, "steps": steps,
            "prompt_positions": [t + wl_naudio * audio_tokens for t in wl_text] if len(wl_text) > 1 else wl_text[0] + wl_naudio * audio_tokens,
            "new_tokens": int(toks.shape[1]), "workspace_gib": round(rt.ws.nbytes() / 2 ** 30, 1), "build_s": round(t_build, 1)}
@@ -910,11 +910,14 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["other_workloads"] = {"note": "BASELINE.json configs 4 and 5 (the 1-GPU half of 5) on this box, micro-batch 64, 3 timed steps "
-                                              "each after the graph warm-up, same step definition; run after the headline legs in this process"}
-            for wl in ("c4", "c5"):
+                                              "each after the graph warm-up, same step definition; run after the headline legs in this process; "
+                                              "c2_beams4 = the headline workload under num_beams=4 (64 prompts prefilled once, 256 beam "
+                                              "sequences decoded)"}
+            for wl in ("c4", "c5", "c2_beams4"):
                 log(f"other workload {wl} ...")
                 try:
-                    out["other_workloads"][wl] = quick_workload(wl, dev)
+                    out["other_workloads"][wl] = (quick_workload("c2", dev, num_beams=4) if wl == "c2_beams4" else
+                                                  quick_workload(wl, dev))
                 except Exception as e:      # a reported side number must never cost the headline line
                     out["other_workloads"][wl] = {"error": f"{type(e).__name__}: {e}"}
                     torch.cuda.empty_cache()
