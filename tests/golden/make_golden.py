@@ -182,13 +182,18 @@ def g5_reference_glue():
             gen_ids = ref.llama_model.generate(inputs_embeds=wrapped, attention_mask=watts, max_new_tokens=10, num_beams=1,
                                                do_sample=False, min_length=1, pad_token_id=tok.pad_token_id,
                                                eos_token_id=tok.eos_token_id)
+            # the same call with the beam knobs the reference forwards to HF (custom_salmon.py:709-714)
+            gen_b3 = ref.generate_output(dict(samples, num_beams=3, length_penalty=1.0))
+            ids_b3 = ref.llama_model.generate(inputs_embeds=wrapped, attention_mask=watts, max_new_tokens=10, num_beams=3,
+                                              do_sample=False, min_length=1, length_penalty=1.0, pad_token_id=tok.pad_token_id,
+                                              eos_token_id=tok.eos_token_id)
         arrs = dict(wrapped=wrapped[0], logits_tail=fwd["logits"][0, -12:], labels=fwd["labels"][0], loss=fwd["loss"],
-                    gen_ids=gen_ids[0])
+                    gen_ids=gen_ids[0], gen_ids_beams3=ids_b3[0])
         if sp is not None:
             arrs["speech"] = sp[0]
         if ee is not None:
             arrs["examples"] = torch.stack(ee[0])
-        cases[case] = {"prompt": prompt, "completion": "positive", "generated_text": gen[0],
+        cases[case] = {"prompt": prompt, "completion": "positive", "generated_text": gen[0], "generated_text_beams3": gen_b3[0],
                        "num_examples": int(samples["num_examples"][0]), "S": int(wrapped.shape[1])}
         save(f"glue_{case}.npz", **arrs)
     # SQA: two audios (question + document) per query and per speech exemplar (custom_salmon.py:135-149,206-241,383-404,444-488)

@@ -136,6 +136,10 @@ def test_prompt_wrap_labels_logits_generate_match_reference_glue(case):
     ids = llm.generate_greedy(wrapped[None], 10, eos_id=tok.eos_token_id, pad_id=tok.pad_token_id)
     assert ids[0].tolist() == a["gen_ids"].tolist()
     assert tok.batch_decode(ids, skip_special_tokens=True)[0] == meta["generated_text"]
+    if "gen_ids_beams3" in a:       # the reference's generate_output with num_beams=3 in the batch dict (custom_salmon.py:709-714)
+        b3 = llm.generate_beam(wrapped[None], 10, eos_id=tok.eos_token_id, pad_id=tok.pad_token_id, num_beams=3, length_penalty=1.0)
+        assert b3[0].tolist() == a["gen_ids_beams3"].tolist()[: b3.shape[1]]
+        assert tok.batch_decode(b3, skip_special_tokens=True)[0] == meta["generated_text_beams3"]
 
 
 @pytest.mark.parametrize("case", ["text_only", "speech_text_ex", "speech_speech_ex"])
