@@ -3,7 +3,7 @@
 //
 // Reference call site: models/custom_salmon.py:704-715 forwards num_beams / length_penalty to HF generate(inputs_embeds=...),
 // models/multi_task_model.py:142 sets them per task.  The algorithm restated here is transformers/generation/utils.py
-// `_beam_search` (early_stopping=False, one EOS id, do_sample=False): per row, the 2K best continuations of the K running
+// `_beam_search` (early_stopping=False, one or two EOS ids, do_sample=False): per row, the 2K (3K with two EOS ids) best continuations of the K running
 // beams; the K best of them that do not stop run on; those among the first K that stop (EOS or the length limit) compete for
 // the K finished slots at sum-of-log-probs / len**length_penalty; a row stops taking finished hypotheses once its best
 // running score / cur_len**length_penalty cannot beat its worst finished one.  The prompt length is 0 for the scorer
@@ -25,7 +25,7 @@ constexpr float BEAM_NEG = -1.0e9f;
 __device__ __forceinline__ bool lex_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
 __global__ __launch_bounds__(256) void beam_step_kernel(
-    const float* __restrict__ logits, int64_t ldl, int rows_per_batch, int V, int K, int T, int step, int eos_id,
+    const float* __restrict__ logits, int64_t ldl, int rows_per_batch, int V, int K, int T, int step, int eos_id, int eos_id2,
     float lenpen_next,   // (step + 1) ** length_penalty: divides a hypothesis finishing now AND the best running score after it
     float* __restrict__ run_score, int* __restrict__ run_seq, float* __restrict__ fin_score, int* __restrict__ fin_seq,
     int* __restrict__ fin_len, int* __restrict__ fin_flag, int* __restrict__ unsat, int* __restrict__ next_ids,
@@ -34,14 +34,15 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
   __shared__ float s_m[BEAM_MAX], s_ls[BEAM_MAX], s_rs[BEAM_MAX];
   __shared__ float s_redv[4];
   __shared__ int s_redi[4];
-  __shared__ float s_cv[2 * BEAM_MAX];
-  __shared__ int s_ci[2 * BEAM_MAX];
+  __shared__ float s_cv[3 * BEAM_MAX];
+  __shared__ int s_ci[3 * BEAM_MAX];
   __shared__ int s_old_run[BEAM_MAX * BEAM_TMAX], s_old_fin[BEAM_MAX * BEAM_TMAX];
   __shared__ int s_run_src[BEAM_MAX];                 // candidate index feeding running beam i
-  __shared__ int s_fin_src[BEAM_MAX];                 // merged index (0..K-1: old finished slot, K..3K-1: candidate) feeding slot i
+  __shared__ int s_fin_src[BEAM_MAX];                 // merged index (0..K-1: old finished slot, K..: candidate) feeding slot i
   __shared__ float s_fin_newscore[BEAM_MAX];
   __shared__ int s_fin_newflag[BEAM_MAX], s_fin_newlen[BEAM_MAX];
 
+  const int NC = (eos_id2 >= 0 ? 3 : 2) * K;          // HF: max(2, 1 + number of EOS ids) * num_beams continuations are kept
   const float* lbase = logits + (int64_t)b * rows_per_batch * ldl;      // beam k's logits: row k (one shared row at step 0)
   const int64_t lstep = rows_per_batch == 1 ? 0 : ldl;
 
@@ -72,10 +73,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
     s_old_fin[i] = fin_seq[(int64_t)b * K * T + i];
   }
 
-  // ---- the 2K best continuations, best first -------------------------------------------------------------------------
+  // ---- the NC best continuations, best first -------------------------------------------------------------------------
   float pv = INFINITY;
   int pi = -1;
-  for (int r = 0; r < 2 * K; ++r) {
+  for (int r = 0; r < NC; ++r) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int k = 0; k < K; ++k) {
@@ -124,29 +125,30 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
   if (tid == 0) {
     const bool last = step + 1 >= T;
     const bool row_open = unsat[b] != 0;
-    bool stops[2 * BEAM_MAX];
-    float runv[2 * BEAM_MAX];
-    for (int j = 0; j < 2 * K; ++j) {
-      stops[j] = last || (s_ci[j] % V) == eos_id;
+    bool stops[3 * BEAM_MAX];
+    float runv[3 * BEAM_MAX];
+    for (int j = 0; j < NC; ++j) {
+      const int tk = s_ci[j] % V;
+      stops[j] = last || tk == eos_id || tk == eos_id2;
       runv[j] = s_cv[j] + (stops[j] ? BEAM_NEG : -0.0f);
     }
     // next running beams: the K best by (score - 1e9 * stops), earlier candidate first on ties
-    bool used[2 * BEAM_MAX] = {};
+    bool used[3 * BEAM_MAX] = {};
     for (int i = 0; i < K; ++i) {
       int best = -1;
-      for (int j = 0; j < 2 * K; ++j)
+      for (int j = 0; j < NC; ++j)
         if (!used[j] && (best < 0 || runv[j] > runv[best])) best = j;
       used[best] = true;
       s_run_src[i] = best;
     }
     // finished slots: old slots first, then the candidates; only the first K candidates may finish, only while the row is open
-    float ms[3 * BEAM_MAX];
-    int mflag[3 * BEAM_MAX];
+    float ms[4 * BEAM_MAX];
+    int mflag[4 * BEAM_MAX];
     for (int k = 0; k < K; ++k) {
       ms[k] = fin_score[b * K + k];
       mflag[k] = fin_flag[b * K + k];
     }
-    for (int j = 0; j < 2 * K; ++j) {
+    for (int j = 0; j < NC; ++j) {
       const bool just = stops[j] && j < K;
       float s = s_cv[j] / lenpen_next;
       s += row_open ? -0.0f : BEAM_NEG;
@@ -154,11 +156,11 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
       ms[K + j] = s;
       mflag[K + j] = just ? 1 : 0;
     }
-    bool mused[3 * BEAM_MAX] = {};
+    bool mused[4 * BEAM_MAX] = {};
     float worst = INFINITY;
     for (int i = 0; i < K; ++i) {
       int best = -1;
-      for (int j = 0; j < 3 * K; ++j)
+      for (int j = 0; j < K + NC; ++j)
         if (!mused[j] && (best < 0 || ms[j] > ms[best])) best = j;
       mused[best] = true;
       s_fin_src[i] = best;
@@ -221,14 +223,16 @@ __global__ __launch_bounds__(256) void kv_copy_spans_kernel(
 }  // namespace
 
 extern "C" int icl_beam_step(const float* logits, int64_t ldl, int32_t rows_per_batch, int32_t B, int32_t V, int32_t num_beams,
-                             int32_t max_new_tokens, int32_t step, int32_t eos_id, float length_penalty, float* run_score,
+                             int32_t max_new_tokens, int32_t step, int32_t eos_id, int32_t eos_id2, float length_penalty,
+                             float* run_score,
                              int32_t* run_seq, float* fin_score, int32_t* fin_seq, int32_t* fin_len, int32_t* fin_flag,
                              int32_t* unsat, int32_t* next_ids, int32_t* parent, void* stream) {
   ICL_CHECK_ARG(logits && run_score && run_seq && fin_score && fin_seq && fin_len && fin_flag && unsat && next_ids && parent,
                 "icl_beam_step: NULL pointer");
   ICL_CHECK_ARG(B > 0 && V > 0 && ldl >= V, "icl_beam_step: bad sizes");
   ICL_CHECK_ARG(num_beams >= 1 && num_beams <= BEAM_MAX, "icl_beam_step: num_beams=%d must be in [1,%d]", num_beams, BEAM_MAX);
-  ICL_CHECK_ARG(V >= 2 * num_beams, "icl_beam_step: V=%d < 2 * num_beams", V);
+  ICL_CHECK_ARG(V >= (eos_id2 >= 0 ? 3 : 2) * num_beams, "icl_beam_step: V=%d < %d * num_beams", V, eos_id2 >= 0 ? 3 : 2);
+  ICL_CHECK_ARG(eos_id2 < 0 || eos_id >= 0, "icl_beam_step: eos_id2 without eos_id");
   ICL_CHECK_ARG(max_new_tokens >= 1 && max_new_tokens <= BEAM_TMAX, "icl_beam_step: max_new_tokens=%d must be in [1,%d]",
                 max_new_tokens, BEAM_TMAX);
   ICL_CHECK_ARG(step >= 0 && step < max_new_tokens, "icl_beam_step: step=%d outside [0,%d)", step, max_new_tokens);
@@ -237,7 +241,7 @@ extern "C" int icl_beam_step(const float* logits, int64_t ldl, int32_t rows_per_
   // python: (cur_len + 1 - prompt_len) ** length_penalty in double, then the f32 tensor is divided by it
   const float lenpen = (float)pow((double)(step + 1), (double)length_penalty);
   hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, rows_per_batch, V, num_beams,
-                     max_new_tokens, step, eos_id, lenpen, run_score, run_seq, fin_score, fin_seq, fin_len, fin_flag, unsat,
+                     max_new_tokens, step, eos_id, eos_id2, lenpen, run_score, run_seq, fin_score, fin_seq, fin_len, fin_flag, unsat,
                      next_ids, parent);
   ICL_CHECK_LAUNCH("icl_beam_step");
   return ICL_OK;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int* src_idx, c
 // ---------------------------------------------------------------------------------------------
 // greedy argmax (lowest index on ties) + EOS/pad bookkeeping; one block per sequence.
 __global__ __launch_bounds__(256) void argmax_eos_kernel(const float* logits, int64_t ldl, int V, int eos_id,
-                                                          int pad_id, int* finished, int* out_tokens,
+                                                          int eos_id2, int pad_id, int* finished, int* out_tokens,
                                                           int out_stride, int step, int* next_ids) {
   __shared__ float smax[4];
   __shared__ int sidx[4];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void argmax_eos_kernel(const float* logits, in
     if (bi == 0x7fffffff) bi = 0;  // all-NaN row: keep a valid id
     int fin = finished[b];
     const int tok = fin ? pad_id : bi;
-    if (tok == eos_id) fin = 1;
+    if (tok == eos_id || tok == eos_id2) fin = 1;
     finished[b] = fin;
     out_tokens[(int64_t)b * out_stride + step] = tok;
     next_ids[b] = tok;
@@ -324,14 +324,14 @@ extern "C" int icl_embed_gather_interleave(const int32_t* src_idx, const void* t
   return ICL_OK;
 }
 
-extern "C" int icl_argmax_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, int32_t eos_id,
+extern "C" int icl_argmax_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, int32_t eos_id, int32_t eos_id2,
                               int32_t pad_id, int32_t* finished, int32_t* out_tokens, int32_t out_stride,
                               int32_t step, int32_t* next_ids, void* stream) {
   ICL_CHECK_ARG(logits && finished && out_tokens && next_ids, "icl_argmax_eos: NULL pointer");
   ICL_CHECK_ARG(B > 0 && V > 0 && ldl >= V, "icl_argmax_eos: bad sizes");
   ICL_CHECK_ARG(step >= 0 && step < out_stride, "icl_argmax_eos: step=%d outside out_stride=%d", step, out_stride);
   hipLaunchKernelGGL(argmax_eos_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, eos_id,
-                     pad_id, finished, out_tokens, out_stride, step, next_ids);
+                     eos_id2, pad_id, finished, out_tokens, out_stride, step, next_ids);
   ICL_CHECK_LAUNCH("icl_argmax_eos");
   return ICL_OK;
 }

@@ -25,7 +25,7 @@ __device__ __forceinline__ unsigned int f32_order_key(float x) {
 
 __global__ __launch_bounds__(256) void sample_eos_kernel(
     const float* logits, int64_t ldl, int V, float* work, int64_t ldw, const int* prev_tokens, int prev_stride,
-    int n_prev, float penalty, float temperature, int top_k, float top_p, const float* uniforms, int eos_id,
+    int n_prev, float penalty, float temperature, int top_k, float top_p, const float* uniforms, int eos_id, int eos_id2,
     int pad_id, int* finished, int* out_tokens, int out_stride, int step, int* next_ids, int* dbg_ids,
     float* dbg_probs, int* dbg_count, int dbg_cap) {
   __shared__ unsigned int hist[256];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void sample_eos_kernel(
     }
     int fin = finished[b];
     const int tok = fin ? pad_id : cidx[pick];
-    if (tok == eos_id) fin = 1;
+    if (tok == eos_id || tok == eos_id2) fin = 1;
     finished[b] = fin;
     out_tokens[(int64_t)b * out_stride + step] = tok;
     next_ids[b] = tok;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void sample_eos_kernel(
 extern "C" int icl_sample_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, float* work, int64_t ldw,
                               const int32_t* prev_tokens, int32_t prev_stride, int32_t n_prev,
                               float repetition_penalty, float temperature, int32_t top_k, float top_p,
-                              const float* uniforms, int32_t eos_id, int32_t pad_id, int32_t* finished,
+                              const float* uniforms, int32_t eos_id, int32_t eos_id2, int32_t pad_id, int32_t* finished,
                               int32_t* out_tokens, int32_t out_stride, int32_t step, int32_t* next_ids,
                               int32_t* dbg_ids, float* dbg_probs, int32_t* dbg_count, int32_t dbg_cap, void* stream) {
   ICL_CHECK_ARG(logits && work && uniforms && finished && out_tokens && next_ids, "icl_sample_eos: NULL pointer");
@@ -193,7 +193,7 @@ extern "C" int icl_sample_eos(const float* logits, int64_t ldl, int32_t B, int32
   ICL_CHECK_ARG(!dbg_count || (dbg_ids && dbg_probs && dbg_cap > 0), "icl_sample_eos: incomplete debug outputs");
   hipLaunchKernelGGL(sample_eos_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, work, ldw,
                      prev_tokens, prev_stride, n_prev, repetition_penalty, temperature, top_k, top_p, uniforms,
-                     eos_id, pad_id, finished, out_tokens, out_stride, step, next_ids, dbg_ids, dbg_probs, dbg_count,
+                     eos_id, eos_id2, pad_id, finished, out_tokens, out_stride, step, next_ids, dbg_ids, dbg_probs, dbg_count,
                      dbg_cap);
   ICL_CHECK_LAUNCH("icl_sample_eos");
   return ICL_OK;

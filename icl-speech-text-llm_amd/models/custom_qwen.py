@@ -5,7 +5,8 @@ Reference behaviour kept: constructor kwargs (:29-40); ``forward`` builds ``labe
 input ids after it (:142-145) and returns {"loss", "logits", "labels"} (:186-197); ``generate_output`` generates 10 new
 tokens and decodes only them with ``skip_special_tokens=True`` (:228-246); ``get_speech_embeddings`` returns four Nones
 (:117-124); ``input_processor`` exposes ``.tokenizer`` and ``.batch_decode``.  LoRA (r=8 on q_proj,k_proj, :71-80) is kept
-un-merged.  Differences: greedy search regardless of the checkpoint's generation_config; rows of different length may
+un-merged.  The checkpoint folder's ``generation_config.json`` is inherited as HF's ``from_pretrained`` does (sampling knobs,
+beams, the EOS id list); without one (synthetic weights) generation is greedy.  Differences: rows of different length may
 share a batch (padding is stripped through ``attention_mask`` and the rows are packed); no fp16 autocast (bf16 inside).
 """
 from __future__ import annotations
@@ -24,6 +25,28 @@ from .base_model import BaseModel
 from .custom_salmon import PackedTreeModule
 
 logger = logging.getLogger(__name__)
+
+
+_GENERATION_KEYS = ("do_sample", "temperature", "top_p", "top_k", "repetition_penalty", "num_beams", "length_penalty",
+                    "eos_token_id", "pad_token_id")
+
+
+def _read_generation_config(model_path) -> Dict[str, Any]:
+    """``generation_config.json`` of a local checkpoint folder -> the knobs this path implements (others are logged)."""
+    import json
+    f = os.path.join(model_path, "generation_config.json") if model_path and os.path.isdir(str(model_path)) else None
+    if not f or not os.path.isfile(f):
+        return {}
+    with open(f) as fh:
+        raw = json.load(fh)
+    cfg = {k: raw[k] for k in _GENERATION_KEYS if raw.get(k) is not None}
+    if isinstance(cfg.get("eos_token_id"), list) and len(cfg["eos_token_id"]) > 2:
+        logger.warning("generation_config names %d EOS ids; the first two are used", len(cfg["eos_token_id"]))
+        cfg["eos_token_id"] = cfg["eos_token_id"][:2]
+    other = sorted(k for k in raw if k not in _GENERATION_KEYS and k not in ("bos_token_id", "transformers_version", "_from_model_config"))
+    if other:
+        logger.info("generation_config keys without effect on this path: %s", other)
+    return cfg
 
 
 class QwenModule(PackedTreeModule):
@@ -180,7 +203,9 @@ class CustomQwen(BaseModel):
                 tokenizer = QwenSpecialTokenizer(cfg.llm.vocab, cfg.audio_token_id, cfg.llm.eos_id, cfg.llm.pad_id)
         self.input_processor = QwenHostProcessor(self, tokenizer)
         self.prompt_template, self.max_txt_len, self.lora = prompt_template, max_txt_len, lora
-        self.generation_config = dict(generation_config or {})
+        # the reference calls generate(max_new_tokens=10) and inherits every other knob from the checkpoint's
+        # generation_config.json (custom_qwen.py:227-233); an explicit ``generation_config`` kwarg wins
+        self.generation_config = dict(_read_generation_config(model_path), **(generation_config or {}))
         self.batch_counter = 0
 
     @property
@@ -252,12 +277,14 @@ class CustomQwen(BaseModel):
         """Batch dict -> ``GenerateResult`` (new token ids, first-step logits on request); see CustomSALMONN.generate_ids."""
         rows, segs, speech, _, _ = self._rows_and_audio(batch)
         # The reference calls generate(max_new_tokens=10) and inherits every other knob from the checkpoint's
-        # generation_config.json (custom_qwen.py:227-233), which is not reachable here: greedy by default; ``generation_config``
-        # (constructor kwarg or batch keys) switches on the sampled tail with the same kernel as the SALMONN path.
+        # generation_config.json (custom_qwen.py:227-233): read at construction when ``model_path`` is a local folder, greedy
+        # otherwise; the ``generation_config`` kwarg and batch keys override it (sampled tail / beams: the SALMONN path's kernels).
         g = {**self.generation_config, **{k: batch[k] for k in ("do_sample", "temperature", "top_p", "top_k", "repetition_penalty",
                                                                    "generator", "num_beams", "length_penalty") if k in batch}}
+        eos = g.get("eos_token_id", self.cfg.llm.eos_id)          # an id or HF's list form (Qwen2-Audio: [151645, 151643])
         res = self.runtime.generate(segs, speech, max_new_tokens=int(batch.get("max_new_tokens", 10)),
-                                    eos_id=self.cfg.llm.eos_id, pad_id=self.cfg.llm.pad_id,
+                                    eos_id=tuple(eos) if isinstance(eos, (list, tuple)) else int(eos),
+                                    pad_id=int(g.get("pad_token_id", self.cfg.llm.pad_id)),
                                     do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),
                                     top_p=float(g.get("top_p", 1.0)), top_k=int(g.get("top_k", 50)),
                                     repetition_penalty=float(g.get("repetition_penalty", 1.0)), generator=g.get("generator"),

@@ -18,7 +18,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libicl_hip.so"))
 
 ICL_BF16, ICL_F32 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 1, 2, 4, 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
@@ -74,12 +74,12 @@ _SIGNATURES = {
     "icl_pack_decode_weights": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "icl_embed_gather_interleave": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                             c_int32, c_int32, c_void_p]),
-    "icl_argmax_eos": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+    "icl_argmax_eos": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                c_int32, c_int32, c_void_p, c_void_p]),
     "icl_sample_eos": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int32,
-                               c_float, c_float, c_int32, c_float, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                               c_float, c_float, c_int32, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
-    "icl_beam_step": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
+    "icl_beam_step": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "icl_kv_copy_spans_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -135,6 +135,16 @@ def _check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load_library().icl_last_error()
         raise IclError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def _eos_pair(eos_id):
+    """int | (int,) | (int, int) -> (eos_id, eos_id2); -1 = unused (HF takes one id or a list; two cover the reference's models)."""
+    if isinstance(eos_id, (tuple, list)):
+        ids = [int(e) for e in eos_id]
+        if not 1 <= len(ids) <= 2:
+            raise ValueError(f"one or two EOS ids are supported, not {ids}")
+        return ids[0], (ids[1] if len(ids) == 2 and ids[1] != ids[0] else -1)
+    return int(eos_id), -1
 
 
 def _stream() -> int:
@@ -346,15 +356,16 @@ def embed_gather_interleave(src_idx, table, speech, out):
     return out
 
 
-def argmax_eos(logits, eos_id: int, pad_id: int, finished, out_tokens, step: int, next_ids, V=None):
+def argmax_eos(logits, eos_id, pad_id: int, finished, out_tokens, step: int, next_ids, V=None):
     _require_gpu(logits, finished, out_tokens, next_ids)
+    e1, e2 = _eos_pair(eos_id)
     _check(load_library().icl_argmax_eos(logits.data_ptr(), logits.stride(0), logits.shape[0],
-                                         logits.shape[1] if V is None else V, eos_id, pad_id, finished.data_ptr(),
+                                         logits.shape[1] if V is None else V, e1, e2, pad_id, finished.data_ptr(),
                                          out_tokens.data_ptr(), out_tokens.stride(0), step, next_ids.data_ptr(),
                                          _stream()), "icl_argmax_eos")
 
 
-def sample_eos(logits, work, uniforms, eos_id: int, pad_id: int, finished, out_tokens, step: int, next_ids, *,
+def sample_eos(logits, work, uniforms, eos_id, pad_id: int, finished, out_tokens, step: int, next_ids, *,
                temperature: float = 1.0, top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.0, V=None,
                debug=None):
     """Sampled decode tail: tokens generated so far (``out_tokens[:, :step]``) feed the repetition penalty; ``uniforms`` f32 [B]
@@ -362,13 +373,14 @@ def sample_eos(logits, work, uniforms, eos_id: int, pad_id: int, finished, out_t
     _require_gpu(logits, work, uniforms, finished, out_tokens, next_ids)
     assert logits.dtype == torch.float32 and work.dtype == torch.float32 and uniforms.dtype == torch.float32
     V = logits.shape[1] if V is None else V
+    e1, e2 = _eos_pair(eos_id)
     dbg = (None, None, None, 0)
     if debug is not None:
         _require_gpu(*debug)
         dbg = (debug[0].data_ptr(), debug[1].data_ptr(), debug[2].data_ptr(), debug[0].shape[1])
     _check(load_library().icl_sample_eos(logits.data_ptr(), logits.stride(0), logits.shape[0], V, work.data_ptr(),
                                          work.stride(0), out_tokens.data_ptr(), out_tokens.stride(0), step,
-                                         repetition_penalty, temperature, top_k, top_p, uniforms.data_ptr(), eos_id, pad_id,
+                                         repetition_penalty, temperature, top_k, top_p, uniforms.data_ptr(), e1, e2, pad_id,
                                          finished.data_ptr(), out_tokens.data_ptr(), out_tokens.stride(0), step,
                                          next_ids.data_ptr(), dbg[0], dbg[1], dbg[2], dbg[3], _stream()), "icl_sample_eos")
 
@@ -394,15 +406,16 @@ class BeamState:
         self.unsat.fill_(1)
 
 
-def beam_step(logits, state: BeamState, step: int, eos_id: int, length_penalty: float, V=None):
+def beam_step(logits, state: BeamState, step: int, eos_id, length_penalty: float, V=None):
     """One beam-search step over ``logits`` f32 [B, V] (step 0: the prompt's distribution, shared by the K beams) or
     [B * K, V] (row b * K + k = running beam k of row b)."""
     _require_gpu(logits, state.run_score)
     assert logits.dtype == torch.float32 and logits.stride(1) == 1
     rows = logits.shape[0] // state.B
     assert rows * state.B == logits.shape[0] and rows in (1, state.K)
+    e1, e2 = _eos_pair(eos_id)
     _check(load_library().icl_beam_step(logits.data_ptr(), logits.stride(0), rows, state.B,
-                                        logits.shape[1] if V is None else V, state.K, state.T, step, eos_id,
+                                        logits.shape[1] if V is None else V, state.K, state.T, step, e1, e2,
                                         float(length_penalty), state.run_score.data_ptr(), state.run_seq.data_ptr(),
                                         state.fin_score.data_ptr(), state.fin_seq.data_ptr(), state.fin_len.data_ptr(),
                                         state.fin_flag.data_ptr(), state.unsat.data_ptr(), state.next_ids.data_ptr(),

@@ -172,7 +172,8 @@ class CausalLMRuntimeMixin:
                 steps = torch.full((sub.step_logits.shape[0], n, sub.step_logits.shape[2]), float("nan"), dtype=F32, device=dev)
                 steps[:, kidx.to(dev)] = sub.step_logits
             return GenerateResult(tokens=toks, first_logits=first, step_logits=steps, dropped=tuple(bad))
-        eos = c.eos_id if eos_id is None else eos_id
+        eos = c.eos_id if eos_id is None else eos_id            # an id, or HF's list form (one or two ids: binding._eos_pair)
+        eos = tuple(int(e) for e in eos) if isinstance(eos, (tuple, list)) else int(eos)
         pad = c.pad_id if pad_id is None else pad_id
         if suppress_eos:
             eos = -1  # benchmark mode: exactly max_new_tokens per row
@@ -292,8 +293,8 @@ class CausalLMRuntimeMixin:
             marks["decode_end"].record()
         out = toks.cpu().to(torch.int64)                                                 # the only D2H of the call
         width = max_new_tokens
-        if eos >= 0:
-            is_eos = out == eos
+        if B._eos_pair(eos)[0] >= 0:
+            is_eos = torch.isin(out, torch.tensor([e for e in B._eos_pair(eos) if e >= 0]))
             first_eos = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((Bn,), max_new_tokens))
             width = int(first_eos.max())
         return GenerateResult(tokens=out[:, :width].contiguous(), first_logits=first,

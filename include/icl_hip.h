@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICL_ABI_VERSION 2
+#define ICL_ABI_VERSION 3
 
 /* error codes */
 #define ICL_OK 0
@@ -222,10 +222,11 @@ int icl_embed_gather_interleave(const int32_t* src_idx, const void* table, const
 
 /* ---- K11: greedy argmax + EOS/pad bookkeeping --------------------------------------------
  * tok = finished[b] ? pad_id : argmax_v logits[b][v] (lowest index on ties);
- * finished[b] |= (tok == eos_id); out_tokens[b*out_stride + step] = tok; next_ids[b] = tok.
+ * finished[b] |= (tok == eos_id || tok == eos_id2); out_tokens[b*out_stride + step] = tok; next_ids[b] = tok.
+ * eos_id2 = -1 when the generation config names one EOS id (HF accepts a list: Qwen2-Audio's is [151643, 151645]).
  * Replaces HF GenerationMixin._sample greedy branch (models/custom_salmon.py:704-720).
  */
-int icl_argmax_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, int32_t eos_id,
+int icl_argmax_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, int32_t eos_id, int32_t eos_id2,
                    int32_t pad_id, int32_t* finished, int32_t* out_tokens, int32_t out_stride,
                    int32_t step, int32_t* next_ids, void* stream);
 
@@ -243,7 +244,7 @@ int icl_argmax_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, int32
  */
 int icl_sample_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, float* work, int64_t ldw,
                    const int32_t* prev_tokens, int32_t prev_stride, int32_t n_prev, float repetition_penalty,
-                   float temperature, int32_t top_k, float top_p, const float* uniforms, int32_t eos_id,
+                   float temperature, int32_t top_k, float top_p, const float* uniforms, int32_t eos_id, int32_t eos_id2,
                    int32_t pad_id, int32_t* finished, int32_t* out_tokens, int32_t out_stride, int32_t step,
                    int32_t* next_ids, int32_t* dbg_ids, float* dbg_probs, int32_t* dbg_count, int32_t dbg_cap,
                    void* stream);
@@ -327,8 +328,8 @@ int icl_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, fl
 /* ---- K11 (beam search): one step of HF's static-shaped beam search + the cache reorder ------------------------------
  * icl_beam_step, per batch row b (num_beams K <= 8, max_new_tokens T <= 64, V >= 2K): log-softmax of the K beams' logits
  *   (row b*rows_per_batch + k; rows_per_batch == 1 at step 0, where the K beams still share the prompt's one distribution) plus
- *   run_score[b][k]; the 2K best continuations (ties: lower beam*V + token); a continuation stops when its token is eos_id
- *   or step + 1 == T.  run_* <- the K best that do not stop (score - 1e9 if only stopping ones are left); fin_* <- the K best of
+ *   run_score[b][k]; the 2K best continuations (3K when eos_id2 >= 0: HF keeps (1 + number of EOS ids) * K; ties: lower
+ *   beam*V + token); a continuation stops when its token is eos_id / eos_id2 or step + 1 == T.  run_* <- the K best that do not stop (score - 1e9 if only stopping ones are left); fin_* <- the K best of
  *   {old finished slots, first-K continuations that stop, scored sum / (step+1)**length_penalty}, taken only while unsat[b];
  *   unsat[b] &= (run_score[b][0] / (step+1)**length_penalty beats the worst finished slot, or a slot is still empty).
  *   next_ids[b*K+i] / parent[b*K+i] = token and absolute source row (b*K + parent beam) of running beam i.
@@ -342,7 +343,7 @@ int icl_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, fl
  *   cache.reorder_cache(beam_idx): only the positions after the prompt differ between the beams of a row.
  */
 int icl_beam_step(const float* logits, int64_t ldl, int32_t rows_per_batch, int32_t B, int32_t V, int32_t num_beams,
-                  int32_t max_new_tokens, int32_t step, int32_t eos_id, float length_penalty, float* run_score,
+                  int32_t max_new_tokens, int32_t step, int32_t eos_id, int32_t eos_id2, float length_penalty, float* run_score,
                   int32_t* run_seq, float* fin_score, int32_t* fin_seq, int32_t* fin_len, int32_t* fin_flag,
                   int32_t* unsat, int32_t* next_ids, int32_t* parent, void* stream);
 int icl_kv_copy_spans_bf16(const void* src, void* dst, int64_t src_layer_stride, int64_t src_seq_stride,

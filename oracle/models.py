@@ -409,7 +409,7 @@ class LlamaOracle:
             tok = lg.argmax(-1)
             tok = torch.where(finished, torch.full_like(tok, pad_id), tok)
             out.append(tok)
-            finished = finished | (tok == eos_id)
+            finished = finished | torch.tensor([int(t) in _eos_set(eos_id) for t in tok])
             if bool(finished.all()) or step == max_new_tokens - 1:
                 break
             e = self.embed(tok)[:, None]
@@ -482,25 +482,32 @@ class LlamaOracle:
                     kept.append((ids, probs))
             tok = torch.where(finished, torch.full((B,), pad_id), torch.tensor(toks))
             out.append(tok)
-            finished = finished | (tok == eos_id)
+            finished = finished | torch.tensor([int(t) in _eos_set(eos_id) for t in tok])
             if bool(finished.all()) or step == max_new_tokens - 1:
                 break
             lg = self.logits(self.forward_hidden(self.embed(tok)[:, None], torch.full((B, 1), T + step), cache))[:, 0]
         return torch.stack(out, dim=1), kept
 
 
+def _eos_set(eos_id) -> frozenset:
+    """HF takes one EOS id or a list of them (generation_config.eos_token_id); negative ids never match."""
+    ids = eos_id if isinstance(eos_id, (tuple, list)) else [eos_id]
+    return frozenset(int(e) for e in ids if int(e) >= 0)
+
+
 class BeamBookkeeping:
     """The scorer of HF beam search (transformers/generation/utils.py `_beam_search`, early_stopping=False, one EOS id,
     do_sample=False, prompt length 0 as with inputs_embeds), one ``step(logits [B*K, V])`` at a time:
-      * 2K continuations are kept per row (best accumulated log-probability first);
+      * 2K continuations (3K with two EOS ids) are kept per row (best accumulated log-probability first);
       * the K best of them that do not stop (EOS or the length limit) run on — a stopping one stays in line at score - 1e9;
       * those among the first K that stop compete for the K finished slots at sum / len**length_penalty, but only while the
         row is open; the row closes once its best running score / cur_len**length_penalty no longer beats its worst
         finished slot (all K slots filled);
       * the search ends when every row is closed or every continuation stopped (length limit)."""
 
-    def __init__(self, Bn: int, K: int, max_new_tokens: int, eos_id: int, length_penalty: float):
-        self.Bn, self.K, self.T, self.eos, self.lp = Bn, K, max_new_tokens, eos_id, length_penalty
+    def __init__(self, Bn: int, K: int, max_new_tokens: int, eos_id, length_penalty: float):
+        self.Bn, self.K, self.T, self.eos, self.lp = Bn, K, max_new_tokens, _eos_set(eos_id), length_penalty
+        self.keep = max(2, 1 + len(self.eos)) * K           # continuations kept per row: (1 + number of EOS ids) * K, at least 2K
         self.neg = torch.tensor(-1.0e9, dtype=torch.float32)
         self.run_seq = [[[] for _ in range(K)] for _ in range(Bn)]
         self.run_score = torch.full((Bn, K), -1.0e9, dtype=torch.float32)
@@ -517,19 +524,19 @@ class BeamBookkeeping:
         logp = F.log_softmax(lg.float(), dim=-1).view(Bn, K, V)
         acc = (logp + self.run_score[:, :, None]).view(Bn, K * V)
         top_v, top_i = torch.sort(acc, dim=1, descending=True, stable=True)      # torch.topk, with ties to the lower beam*V + token
-        top_v, top_i = top_v[:, : 2 * K], top_i[:, : 2 * K]
+        top_v, top_i = top_v[:, : self.keep], top_i[:, : self.keep]
         parents = torch.zeros(Bn, K, dtype=torch.long)
         toks = torch.zeros(Bn, K, dtype=torch.long)
         lenpen = float(step + 1) ** self.lp
         all_stop = True
         for b in range(Bn):
             cand = []
-            for j in range(2 * K):
+            for j in range(self.keep):
                 par, tok = int(top_i[b, j]) // V, int(top_i[b, j]) % V
-                stops = (tok == self.eos) or (step + 1 >= self.T)
+                stops = (tok in self.eos) or (step + 1 >= self.T)
                 cand.append((top_v[b, j], par, tok, stops, self.run_seq[b][par] + [tok]))
             all_stop = all_stop and all(c[3] for c in cand)
-            order = sorted(range(2 * K), key=lambda j: (-float(cand[j][0] + (NEG if cand[j][3] else 0.0)), j))[:K]
+            order = sorted(range(self.keep), key=lambda j: (-float(cand[j][0] + (NEG if cand[j][3] else 0.0)), j))[:K]
             merged = list(self.fin[b])
             for j, (v, par, tok, stops, seq) in enumerate(cand):
                 sc = v / lenpen

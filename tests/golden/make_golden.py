@@ -727,6 +727,18 @@ def g16_beam_search():
     run("eos_mid5_lp2", emb, 5, 2.0, int(free[1, 4]))
     run("one_row_eos3", emb[1:], 3, 1.0, int(free[1, 1]))
     run("short3", emb, 3, 1.0, int(free[0, 1]), max_new=3)
+    # HF's list form of eos_token_id (Qwen2-Audio's generation_config names two): 3K continuations are kept per row
+    two = [int(free[0, 3]), int(free[1, 2])]
+    for name, nb, lp in (("two_eos4", 4, 1.0), ("two_eos2_lpneg", 2, -1.0), ("two_eos3_lp2", 3, 2.0)):
+        with torch.no_grad():
+            r = m.generate(inputs_embeds=emb, attention_mask=att, max_new_tokens=10, do_sample=False, num_beams=nb, min_length=1,
+                           length_penalty=lp, pad_token_id=259, eos_token_id=two, return_dict_in_generate=True, output_scores=True)
+        out[name + "_seq"], out[name + "_score"] = r.sequences, r.sequences_scores
+        out[name + "_knobs"] = np.array([nb, lp, two[0], 10, two[1]], dtype=np.float64)
+    with torch.no_grad():
+        g2 = m.generate(inputs_embeds=emb, attention_mask=att, max_new_tokens=10, do_sample=False, num_beams=1, min_length=1,
+                        pad_token_id=259, eos_token_id=[int(free[0, 3]), 221])      # 221: row 1's first greedy token
+    out["two_eos_greedy_seq"], out["two_eos_greedy_eos"] = g2, np.array([int(free[0, 3]), 221])
     save("beam_tiny.npz", **out)
 
 

@@ -534,6 +534,9 @@ def test_argmax_eos(B):
     assert nxt.tolist() == [123, 2, 7, 32000]
     assert fin.tolist() == [0, 1, 0, 1]
     assert (toks[:, :3] == -1).all()
+    fin2 = torch.zeros(Bn, dtype=torch.int32, device=DEV)       # HF's list form of eos_token_id: either id ends the row
+    B.argmax_eos(logits, (2, 7), 32000, fin2, toks, 4, nxt)
+    assert toks[:, 4].tolist() == [123, 2, 7, 32000] and fin2.tolist() == [0, 1, 1, 0]
 
 
 def test_lora_down(B):
@@ -870,7 +873,8 @@ def test_sample_eos_matches_oracle_and_hf_golden():
 
 # ---- beam search: the step kernel against the oracle's scorer, the span copy against indexing -----------------------------------
 @pytest.mark.parametrize("Bn,K,V,T,lp,eos", [(3, 4, 260, 6, 1.0, 17), (2, 8, 32001, 5, 2.0, 2), (5, 1, 40, 4, 0.0, 3),
-                                              (2, 3, 1000, 64, -1.0, 5), (1, 2, 4, 3, 1.0, 0)])
+                                              (2, 3, 1000, 64, -1.0, 5), (1, 2, 4, 3, 1.0, 0), (3, 4, 300, 6, 1.0, (17, 40)),
+                                              (2, 8, 32001, 4, -1.0, (2, 31999)), (2, 2, 6, 3, 1.0, (0, 5))])
 def test_beam_step_matches_oracle_scorer(B, Bn, K, V, T, lp, eos):
     """A whole search on synthetic logits that depend on each beam's history (a tiny recurrent stand-in for the decoder, advanced
     along the chosen parents): `icl_beam_step` and oracle.BeamBookkeeping must choose the same parents / tokens at every step and
@@ -881,7 +885,7 @@ def test_beam_step_matches_oracle_scorer(B, Bn, K, V, T, lp, eos):
     A = torch.randn(Hd, Hd, generator=g) * 0.6
     E = torch.randn(V, Hd, generator=g)
     U = torch.randn(Hd, V, generator=g) * 1.5
-    U[:, eos] += 0.8                                    # EOS is a frequent contender
+    U[:, list(eos) if isinstance(eos, tuple) else eos] += 0.8     # EOS is a frequent contender (a tuple: HF's list of EOS ids, 3K kept)
     h = torch.randn(Bn, Hd, generator=g)
     state = B.BeamState(lambda name, shape, dt: torch.empty(shape, dtype=dt, device=DEV), Bn, K, T, pad_id=V - 1)
     bk = om.BeamBookkeeping(Bn, K, T, eos, lp)

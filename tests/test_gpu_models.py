@@ -229,6 +229,14 @@ def test_generate_eos_and_pad_semantics(env):
     eos0 = int(base.tokens[0, 0])
     res1 = rt.generate(prompts[:1], None, max_new_tokens=6, eos_id=eos0)
     assert res1.tokens.shape == (1, 1) and int(res1.tokens[0, 0]) == eos0
+    # HF's list form of eos_token_id (Qwen2-Audio's generation_config names two): either id ends its row
+    pair = (int(base.tokens[0, 3]), int(base.tokens[1, 1]))
+    res2 = rt.generate(prompts, None, max_new_tokens=6, eos_id=pair, pad_id=cfg.llama.pad_id)
+    want = [ob.generate_greedy(e, 6, list(pair), cfg.llama.pad_id)[0].tolist() for e in embs]
+    width = max(len(w) for w in want)
+    assert res2.tokens.shape[1] == width
+    for i, w in enumerate(want):
+        assert res2.tokens[i, :len(w)].tolist() == w and all(t == cfg.llama.pad_id for t in res2.tokens[i, len(w):].tolist())
 
 
 def test_decode_graph_replay_matches_eager(env):
@@ -408,7 +416,7 @@ def _beam_replay(dbg, Bn, K, T, eos, lp, pad):
 
 
 @pytest.mark.parametrize("K,lp,eos_from", [(3, 1.0, None), (4, 1.0, (0, 2)), (2, 0.0, (1, 1)), (4, 2.0, (2, 3)), (3, -1.0, (0, 1)),
-                                           (1, 1.0, None)])
+                                           (1, 1.0, None), (3, 1.0, ((0, 2), (1, 1))), (2, -1.0, ((2, 1), (0, 3)))])
 def test_beam_search_matches_oracle(env, K, lp, eos_from):
     """num_beams > 1 (models/custom_salmon.py:709-714 -> HF _beam_search).  Three checks on ragged prompts:
     (1) the oracle's scorer replayed on the logits the GPU search scored reproduces the GPU's choices at every step (parents,
@@ -425,13 +433,16 @@ def test_beam_search_matches_oracle(env, K, lp, eos_from):
     eos = -1
     if eos_from is not None:            # an EOS some hypothesis meets: the token the unconstrained search puts at (row, step)
         free = rt.generate(prompts, None, max_new_tokens=T, suppress_eos=True, num_beams=K, length_penalty=lp)
-        eos = int(free.tokens[eos_from[0], eos_from[1]])
+        if isinstance(eos_from[0], tuple):          # two EOS ids (HF's list form): 3K continuations per row
+            eos = tuple(int(free.tokens[r, t]) for r, t in eos_from)
+        else:
+            eos = int(free.tokens[eos_from[0], eos_from[1]])
     dbg = {}
     if K == 1:                          # generate() sends one beam down the greedy path; the beam machinery must agree with it
         res = rt._generate_beam(prompts, None, T, eos, pad, 1, lp, True, 64, debug=dbg)
     else:
         res = rt.generate(prompts, None, max_new_tokens=T, eos_id=eos, pad_id=pad, num_beams=K, length_penalty=lp,
-                          want_first_logits=True, beam_debug=dbg, suppress_eos=eos < 0)
+                          want_first_logits=True, beam_debug=dbg, suppress_eos=eos == -1)
     Bn = len(lens)
     assert len(dbg["logits"]) == T and dbg["logits"][0].shape[0] == Bn and dbg["logits"][1].shape[0] == Bn * K
     # (1) bookkeeping replay
@@ -467,7 +478,7 @@ def test_beam_search_matches_oracle(env, K, lp, eos_from):
         same += int(g == ids)
     print(f"free-running oracle agrees on {same}/{Bn} rows")
     if K == 1:      # one beam is greedy search (HF's own equivalence): the GPU's greedy path must give the same ids
-        greedy = rt.generate(prompts, None, max_new_tokens=T, eos_id=eos, pad_id=pad, suppress_eos=eos < 0)
+        greedy = rt.generate(prompts, None, max_new_tokens=T, eos_id=eos, pad_id=pad, suppress_eos=eos == -1)
         assert greedy.tokens.tolist() == res.tokens.tolist()
 
 

@@ -633,3 +633,23 @@ def test_inline_asm_in_csrc_is_limited_to_memory_and_wait_instructions():
                     if ins.split()[0] not in allow:
                         bad.append((os.path.basename(f), ins[:60]))
     assert seen > 10 and not bad, bad
+
+
+def test_qwen_generation_config_json_is_inherited(tmp_path):
+    """The reference calls generate(max_new_tokens=10) and inherits the rest from the checkpoint folder's generation_config.json
+    (models/custom_qwen.py:227-233, HF from_pretrained): the plugin reads the same file; implemented knobs only, EOS list kept."""
+    from icl_speech_text_llm_amd.models.custom_qwen import _read_generation_config
+    assert _read_generation_config("Qwen/Qwen2-Audio-7B-Instruct") == {} and _read_generation_config(None) == {}
+    (tmp_path / "generation_config.json").write_text(json.dumps({
+        "bos_token_id": 151643, "do_sample": True, "eos_token_id": [151645, 151643], "pad_token_id": 151643,
+        "repetition_penalty": 1.1, "temperature": 0.7, "top_k": 20, "top_p": 0.5, "transformers_version": "4.38.1",
+        "no_repeat_ngram_size": 0}))
+    g = _read_generation_config(str(tmp_path))
+    assert g == {"do_sample": True, "temperature": 0.7, "top_p": 0.5, "top_k": 20, "repetition_penalty": 1.1,
+                 "eos_token_id": [151645, 151643], "pad_token_id": 151643}
+    (tmp_path / "generation_config.json").write_text(json.dumps({"eos_token_id": [5, 6, 7], "num_beams": 4, "length_penalty": 0.5}))
+    assert _read_generation_config(str(tmp_path)) == {"num_beams": 4, "length_penalty": 0.5, "eos_token_id": [5, 6]}
+    from icl_speech_text_llm_amd.runtime.binding import _eos_pair
+    assert _eos_pair(2) == (2, -1) and _eos_pair([151645, 151643]) == (151645, 151643) and _eos_pair((7, 7)) == (7, -1)
+    with pytest.raises(ValueError):
+        _eos_pair([1, 2, 3])

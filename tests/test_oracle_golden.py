@@ -70,10 +70,14 @@ def test_llama_forward_loss_and_generate_match_hf():
     # EOS at step 0 -> width-1 output (min_length=1 is a no-op with inputs_embeds)
     g0 = llm.generate_greedy(emb[:1], 10, eos_id=int(a["eos0"]), pad_id=259)
     assert g0.tolist() == a["gen_eos0"].tolist() and g0.shape == (1, 1)
+    # eos_token_id as a list (generation_config.json of Qwen2-Audio names two ids): either one ends a row
+    g = np.load(os.path.join(G, "beam_tiny.npz"))
+    two = llm.generate_greedy(emb, 10, eos_id=[int(t) for t in g["two_eos_greedy_eos"]], pad_id=259)
+    assert two.tolist() == g["two_eos_greedy_seq"].tolist()
 
 
 BEAM_CASES = ["free4", "free3_lp2", "free2_lp0", "eos_mid4", "eos_first4", "eos_mid4_lpneg", "eos_mid5_lp2", "one_row_eos3",
-              "short3"]
+              "short3", "two_eos4", "two_eos2_lpneg", "two_eos3_lp2"]
 
 
 @pytest.mark.parametrize("case", BEAM_CASES)
@@ -85,10 +89,12 @@ def test_beam_search_matches_hf(case):
     g = np.load(os.path.join(G, "beam_tiny.npz"))
     llm = om.LlamaOracle(sd, n_heads=2, rms_eps=1e-5)
     emb = torch.from_numpy(a["emb"])
-    K, lp, eos, max_new = g[case + "_knobs"]
+    K, lp, eos, max_new = g[case + "_knobs"][:4]
+    if len(g[case + "_knobs"]) > 4:                # HF's list form of eos_token_id
+        eos = [int(eos), int(g[case + "_knobs"][4])]
     want = g[case + "_seq"]
     e = emb[1:] if want.shape[0] == 1 else emb
-    ids, score = llm.generate_beam(e, int(max_new), eos_id=int(eos), pad_id=259, num_beams=int(K), length_penalty=float(lp),
+    ids, score = llm.generate_beam(e, int(max_new), eos_id=eos if isinstance(eos, list) else int(eos), pad_id=259, num_beams=int(K), length_penalty=float(lp),
                                    return_scores=True)
     assert ids.tolist() == want.tolist()
     assert np.abs(score.numpy() - g[case + "_score"]).max() < 2e-4 * max(1.0, float(np.abs(g[case + "_score"]).max()))
