@@ -496,3 +496,35 @@ def test_beam_search_in_row_groups_matches_one_pass(env):
     assert grouped.tokens.tolist() == one.tokens.tolist() and grouped.first_logits.shape[0] == 5
     with pytest.raises(NotImplementedError):
         rt.generate(prompts, None, max_new_tokens=5, num_beams=3, do_sample=True)
+
+
+def test_generate_edge_cases(env):
+    """The ends of the input domain: a prompt that fills the position table to its last slot, one-token prompts next to it,
+    a single new token, and the inputs that must be refused before anything is launched."""
+    from icl_speech_text_llm_amd.runtime.salmonn import speech_segment
+    from oracle import models as om
+    cfg, sd, rt = env
+    T = 4
+    full = cfg.llama.max_pos - T                       # prompt + new tokens == max_pos exactly (2048: a multiple of the cache step)
+    prompts = _prompts(cfg, [full, 1, 65], seed=31)
+    res = rt.generate(prompts, None, max_new_tokens=T, suppress_eos=True, want_first_logits=True)
+    assert res.tokens.shape == (3, T)
+    ob = _llama_oracle(cfg, sd, om.bf16_round)
+    for i in (0, 1):                                    # the longest and the shortest row against the oracle (first-step logits)
+        emb = ob.embed(torch.tensor(prompts[i][0]))[None]
+        _, first = ob.generate_greedy(emb, 1, -1, cfg.llama.pad_id, return_first_logits=True)
+        r = _rel(res.first_logits[i], first[0])
+        print(f"edge rows: prompt of {len(prompts[i][0])} positions, first-step logits rel {r:.2e}")
+        assert r < TOL_LOGITS_REL
+    one = rt.generate(prompts[1:], None, max_new_tokens=1, suppress_eos=True)
+    assert one.tokens.shape == (2, 1) and one.tokens[:, 0].tolist() == res.tokens[1:, 0].tolist()
+    with pytest.raises(ValueError, match="exceed max_pos"):
+        rt.generate(_prompts(cfg, [full + 1], seed=31), None, max_new_tokens=T)
+    with pytest.raises(ValueError, match="empty prompt"):
+        rt.generate([[[]]], None, max_new_tokens=T)
+    with pytest.raises(ValueError, match="outside the vocabulary"):
+        rt.generate([[[3, cfg.llama.vocab]]], None, max_new_tokens=T)
+    with pytest.raises(ValueError, match="speech segment"):
+        rt.generate([[[3, 4], speech_segment(0, 5)]], torch.zeros(1, 4, cfg.llama.hidden, device=DEV), max_new_tokens=T)
+    with pytest.raises(ValueError, match="num_beams"):
+        rt.generate(prompts[1:], None, max_new_tokens=T, num_beams=0)
