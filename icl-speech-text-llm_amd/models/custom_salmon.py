@@ -383,18 +383,19 @@ class CustomSALMONN(BaseModel):
                         specs.append(ex_spec[b, e]); owners.append((b, e))
             emb = rt.encode_speech(None, None, spectrogram=torch.stack(specs).to(self.device))
         emb = emb.clone()   # detach from the runtime's reusable workspace
+        wins = rt.last_audio_windows      # tokens per audio: ntok (88) unless a clip / its collated width exceeds 30 s
         speech_embeds = speech_atts = example_embeds = example_atts = None
-        ones = torch.ones(ntok, dtype=torch.long, device=emb.device)
         if has_main:
-            speech_embeds = emb[:B]
-            speech_atts = torch.ones(B, ntok, dtype=torch.long, device=emb.device)
+            wm = wins[0] if use_wav else ntok           # main rows share one collated width, hence one token count
+            speech_embeds = emb[:B, :wm]
+            speech_atts = torch.ones(B, wm, dtype=torch.long, device=emb.device)
         if has_ex:
             example_embeds = [[] for _ in range(B)]
             example_atts = [[] for _ in range(B)]
             for i, (b, e) in enumerate(owners):
                 if e >= 0:
-                    example_embeds[b].append(emb[i])
-                    example_atts[b].append(ones)
+                    example_embeds[b].append(emb[i, :wins[i]])
+                    example_atts[b].append(torch.ones(wins[i], dtype=torch.long, device=emb.device))
         logger.debug("Speech embedding generation took %.3f s", time.time() - t0)
         return speech_embeds, speech_atts, example_embeds, example_atts
 
@@ -402,7 +403,6 @@ class CustomSALMONN(BaseModel):
         """SQA batches (reference :312-323, :383-404, :444-488): question and document audio of the query and of every speech
         exemplar, all encoded in ONE batched kernel chain; returns ``((q, d), (q_atts, d_atts), [[(q_e, d_e)…]…], atts)``."""
         rt = self.runtime
-        ntok = rt.tokens_per_audio
         q_wav, d_wav = samples.get("question_raw_wav"), samples.get("document_raw_wav")
         eq_wav, ed_wav = samples.get("example_question_wavs"), samples.get("example_document_wavs")
         has_main = q_wav is not None and d_wav is not None
@@ -433,21 +433,23 @@ class CustomSALMONN(BaseModel):
         for i, r in enumerate(rows):
             wav[i, :r.shape[0]] = r.to(device=self.device, dtype=torch.float32)
         emb = rt.encode_speech(wav, valid, padded_lens=padded).clone()
-        ones = torch.ones(ntok, dtype=torch.long, device=emb.device)
+        wins = rt.last_audio_windows      # tokens per audio: ntok (88) unless a collated width exceeds 30 s
         speech_embeds = speech_atts = example_embeds = example_atts = None
         if has_main:
             B = q_wav.shape[0]
-            speech_embeds = (emb[:B], emb[B:2 * B])
-            speech_atts = (torch.ones(B, ntok, dtype=torch.long, device=emb.device),) * 2
+            wq, wd = wins[0], wins[B]                  # one collated width per side, hence one token count per side
+            speech_embeds = (emb[:B, :wq], emb[B:2 * B, :wd])
+            speech_atts = (torch.ones(B, wq, dtype=torch.long, device=emb.device), torch.ones(B, wd, dtype=torch.long, device=emb.device))
         if has_ex:
             B = eq_wav.shape[0]
             slot: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
             for i, (b, side, e) in enumerate(owners):
                 if e >= 0:
-                    slot.setdefault((b, e), {})[side] = emb[i]
+                    slot.setdefault((b, e), {})[side] = emb[i, :wins[i]]
             example_embeds = [[(slot[(b, e)]["q"], slot[(b, e)]["d"]) for e in sorted(k[1] for k in slot if k[0] == b)]
                               for b in range(B)]
-            example_atts = [[(ones, ones) for _ in row] for row in example_embeds]
+            example_atts = [[tuple(torch.ones(t.shape[0], dtype=torch.long, device=emb.device) for t in pair) for pair in row]
+                            for row in example_embeds]
         return speech_embeds, speech_atts, example_embeds, example_atts
 
     # ---- prompt wrap ------------------------------------------------------------------------------------

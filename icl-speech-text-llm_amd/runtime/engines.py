@@ -206,7 +206,9 @@ class BeatsHIP:
         nf = [self.frames(L) for L in padded_lens]
         T = [(f // 16) * 8 for f in nf]
         assert min(T) > 0, "audio shorter than one BEATs patch (16 frames)"
-        assert max(T) <= w.rel_span, "audio longer than the packed relative-position span"
+        # relative positions beyond the packed span are clamped by the kernel: exact once the span covers max_distance, where
+        # the bucket function has saturated (BEATs: 800 < 1504), so clips longer than 30 s need no larger table
+        assert max(T) <= w.rel_span or w.rel_span > c.max_distance, "audio longer than the packed relative-position span"
         cu_h = [0]
         for t in T:
             cu_h.append(cu_h[-1] + t)
@@ -294,17 +296,51 @@ class SpeechQFormerHIP:
 
     def forward(self, ws: Workspace, speech: torch.Tensor, n: int, audio: Optional[torch.Tensor] = None,
                 audio_cu: Optional[List[int]] = None) -> torch.Tensor:
-        """speech f32 [n*1500, dw] (Whisper out), audio f32 [sum T_a, db] packed (BEATs out) -> f32 [n*88, H_llm]."""
+        """speech f32 [n*1500, dw] (Whisper out), audio f32 [sum T_a, db] packed (BEATs out) -> f32 [n*W, H_llm], W = the largest
+        window count of the batch (``last_windows[a]`` rows of audio a are its tokens, the rest zero).  SALMONN pads the SHORTER
+        stream with zero frames (external package, `_encode_auditory_feature`; call site models/custom_salmon.py:420-430): a
+        clip of up to 30 s has 1500 frames -> 88 windows; a longer one keeps its T_a > 1500 BEATs frames next to Whisper's
+        1500 (the feature extractor truncates) + zeros -> (T_a - 17) // 17 + 1 windows."""
+        T0 = 1500
+        frames = [T0] * n if audio is None else [max(T0, audio_cu[a + 1] - audio_cu[a]) for a in range(n)]
+        self.last_windows = [self.n_windows(f) for f in frames]
+        if all(f == T0 for f in frames):
+            return self._run(ws, speech, n, audio, audio_cu, T0)
+        Wmax = max(self.last_windows)
+        full = ws.get("qf_out_ragged", (n, Wmax, self.llm_hidden), F32)
+        full.zero_()
+        a0 = 0
+        while a0 < n:                                  # runs of consecutive audios with the same frame count
+            a1 = a0 + 1
+            while a1 < n and frames[a1] == frames[a0]:
+                a1 += 1
+            cu = [x - audio_cu[a0] for x in audio_cu[a0:a1 + 1]]
+            out = self._run(ws, speech[a0 * T0:a1 * T0], a1 - a0, audio[audio_cu[a0]:audio_cu[a1]], cu, frames[a0])
+            nw = self.n_windows(frames[a0])
+            full[a0:a1, :nw].copy_(out.view(a1 - a0, nw, self.llm_hidden))
+            a0 = a1
+        return full.view(n * Wmax, self.llm_hidden)
+
+    def _run(self, ws: Workspace, speech: torch.Tensor, n: int, audio: Optional[torch.Tensor], audio_cu: Optional[List[int]],
+             T: int) -> torch.Tensor:
+        """n audios of T >= 1500 frames each (Whisper's 1500 + zero frames; BEATs' T_a <= T + zero frames) -> [n * n_windows(T), H_llm]."""
         w, c = self.w, self.w.cfg
-        T, dw, db, hq = 1500, self.whisper_d, self.beats_d, c.hidden
+        dw, db, hq = self.whisper_d, self.beats_d, c.hidden
         C = dw + (db if audio is not None else 0)
         assert C == c.enc_width, f"Q-Former encoder width {c.enc_width} != {C}"
         cat = ws.get("qf_cat", (n * T, C), BF16)
-        B.layernorm(speech, w.ln_speech_g, w.ln_speech_b, cat, 1e-5, N=dw)
-        if audio is not None:
-            cat[:, dw:].zero_()   # F.pad of the shorter BEATs stream (memset; rows past T_a stay zero)
+        if T == 1500:
+            B.layernorm(speech, w.ln_speech_g, w.ln_speech_b, cat, 1e-5, N=dw)
+        else:
+            cat.zero_()                               # F.pad of the Whisper stream: frames 1500 .. T-1 are zero AFTER ln_speech
             for a in range(n):
-                ta = min(audio_cu[a + 1] - audio_cu[a], T)
+                B.layernorm(speech[a * 1500:(a + 1) * 1500], w.ln_speech_g, w.ln_speech_b, cat[a * T:a * T + 1500], 1e-5, N=dw)
+        if audio is not None:
+            if T == 1500:
+                cat[:, dw:].zero_()   # F.pad of the shorter BEATs stream (memset; rows past T_a stay zero)
+            for a in range(n):
+                ta = audio_cu[a + 1] - audio_cu[a]
+                assert ta <= T
                 B.layernorm(audio[audio_cu[a]:audio_cu[a] + ta], w.ln_audio_g, w.ln_audio_b,
                             cat[a * T:a * T + ta, dw:], 1e-5, N=db)
         nw = self.n_windows(T)

@@ -427,7 +427,8 @@ class SalmonnRuntime(CausalLMRuntimeMixin):
         """raw_wav f32 [n, L] (zero padded; host or device), wav_lens valid samples per audio.
         spectrogram (optional, f32 [n, n_mels, 3000]): use the caller's log-mel instead of K1.
         padded_lens: length the reference's BEATs would see per audio (defaults to wav_lens: batch-1 semantics).
-        Returns speech embeddings f32 [n, 88, H_llm] on the device (atts are all ones in the reference)."""
+        Returns speech embeddings f32 [n, 88, H_llm] on the device (atts are all ones in the reference); with a clip longer than
+        30 s in the batch: [n, W_max, H_llm] and ``last_audio_windows`` = tokens per audio."""
         ws, dev = self.ws, self.device
         if raw_wav is not None:
             raw_wav = raw_wav.to(device=dev, dtype=F32)
@@ -450,7 +451,10 @@ class SalmonnRuntime(CausalLMRuntimeMixin):
             padded = [int(x) for x in (padded_lens if padded_lens is not None else wav_lens)]
             audio, cu, _ = self.beats.forward(ws, raw_wav, padded, wav_lens)
         out = self.qformer.forward(ws, speech, n, audio, cu)
-        return out.view(n, self.tokens_per_audio, self.cfg.llama.hidden)
+        # tokens per audio: 88 up to 30 s; a longer clip keeps its extra BEATs frames (SALMONN pads the shorter stream) and gets
+        # more windows — rows past last_audio_windows[a] of audio a are zero padding, not tokens
+        self.last_audio_windows = list(self.qformer.last_windows)
+        return out.view(n, max(self.last_audio_windows), self.cfg.llama.hidden)
 
     def log_mel(self, raw_wav: torch.Tensor, wav_lens: Sequence[int]) -> torch.Tensor:
         """K1 alone: f32 [n, n_mels, 3000] (the ``spectrogram`` batch key of the reference's processor)."""

@@ -528,3 +528,27 @@ def test_generate_edge_cases(env):
         rt.generate([[[3, 4], speech_segment(0, 5)]], torch.zeros(1, 4, cfg.llama.hidden, device=DEV), max_new_tokens=T)
     with pytest.raises(ValueError, match="num_beams"):
         rt.generate(prompts[1:], None, max_new_tokens=T, num_beams=0)
+
+
+def test_encode_speech_edge_lengths(env):
+    """0.2 s (BEATs' shortest useful clip: 18 fbank frames -> one row of 16x16 patches), exactly 30 s, and more than 30 s in ONE ragged
+    batch, each against the oracle run on that clip alone (batch-1 semantics of the reference's CLI).  Past 30 s Whisper's feature
+    extractor truncates to 3000 frames while BEATs sees the whole clip, and SALMONN pads the SHORTER stream with zero frames:
+    the clip keeps its 1536 BEATs frames and gets 90 windows instead of 88."""
+    from oracle import audio_frontend as af, models as om
+    cfg, sd, rt = env
+    lens = [3200, 480000, 480000 + 12345]
+    wav = _wavs(lens)
+    got = rt.encode_speech(wav, lens).clone()
+    assert rt.last_audio_windows == [88, 88, 90] and got.shape == (3, 90, cfg.llama.hidden) and bool(torch.isfinite(got).all())
+    assert float(got[:2, 88:].abs().max()) == 0.0          # rows past an audio's own windows are padding
+    for i, n in enumerate(lens):
+        spec = torch.from_numpy(af.whisper_logmel(wav[i, :n].numpy()))[None]
+        ref_b = om.salmonn_encode_speech(sd, spec, wav[i:i + 1, :n], [n], cfg.whisper.n_heads, rnd=om.bf16_round,
+                                         beats_cfg=dict(n_heads=cfg.beats.n_heads), qformer_heads=cfg.qformer.n_heads)
+        assert ref_b.shape[1] == rt.last_audio_windows[i]
+        eb = _rel(got[i, :ref_b.shape[1]], ref_b[0])
+        print(f"encode_speech edge [{n} samples, {ref_b.shape[1]} windows]: rel err vs bf16-rounding oracle {eb:.2e}")
+        assert eb < 1.5e-3
+    again = rt.encode_speech(wav[:2], lens[:2])             # back to the uniform path: 88 windows, same values
+    assert again.shape == (2, 88, cfg.llama.hidden) and torch.equal(again, got[:2, :88])

@@ -102,6 +102,22 @@ def test_beam_search_through_the_plugins(model):
     assert bb["num_beams"] == 2 and len(out) == 2
 
 
+def test_clips_longer_than_30_seconds_keep_their_extra_windows(model):
+    """SALMONN pads the SHORTER of the Whisper / BEATs streams (external package; call site models/custom_salmon.py:420-430): the
+    feature extractor truncates Whisper's input to 30 s = 1500 frames, BEATs sees the whole collated waveform, so a 30.8 s batch
+    carries 1536 frames -> 90 speech tokens per clip instead of 88, in the prompt and in the generated answer's context."""
+    b = _batch(model, "speech", n=2, bs=2, num_examples=1, secs=30.8, vary=False)
+    b = {k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    sp, sa, ee, ea = model.get_speech_embeddings(dict(b))
+    assert sp.shape[:2] == (2, 90) and sa.shape == (2, 90) and ee[0][0].shape[0] == 90 and ea[0][0].shape[0] == 90
+    assert bool(torch.isfinite(sp).all())
+    out = model.generate_output(dict(b))
+    assert len(out) == 2
+    short = _batch(model, "speech", n=2, bs=2, num_examples=1, secs=3.0, vary=False)
+    short = {k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in short.items()}
+    assert model.get_speech_embeddings(short)[0].shape[:2] == (2, 88)
+
+
 def test_get_speech_embeddings_matches_oracle_batch1(model):
     from oracle import audio_frontend as af, models as om
     b = _batch(model, "speech", n=1, bs=1, num_examples=2, vary=True)
