@@ -183,6 +183,8 @@ class CausalLMRuntimeMixin:
                 raise ValueError(f"num_beams must be >= 1, not {num_beams}")
             if do_sample or repetition_penalty != 1.0 or want_step_logits:
                 raise NotImplementedError("beam search runs without sampling, repetition penalty or a per-step logits trace")
+            if num_beams > 8 or max_new_tokens > 64:      # the step kernel's state (include/icl_hip.h); refused before any launch
+                raise ValueError(f"beam search supports num_beams <= 8 and max_new_tokens <= 64 (got {num_beams}, {max_new_tokens})")
             return self._generate_beam(prompts, speech, max_new_tokens, eos, pad, num_beams, float(length_penalty),
                                        want_first_logits, cache_len_multiple, debug=beam_debug)
         h, lens = self.embed_prompts(prompts, speech)
@@ -227,7 +229,9 @@ class CausalLMRuntimeMixin:
         nxt = ws.get("gen_next", (Bn,), I32)
         sampled = do_sample or repetition_penalty != 1.0
         if sampled:
-            knobs = ((float(temperature), int(top_k), float(top_p)) if do_sample else (1.0, 1, 1.0)) + (float(repetition_penalty),)
+            # HF's TopKLogitsWarper clamps top_k to the vocabulary; 0 / None switch it off (= every token a candidate)
+            top_k = c.vocab if not top_k else min(int(top_k), c.vocab)
+            knobs = ((float(temperature), top_k, float(top_p)) if do_sample else (1.0, 1, 1.0)) + (float(repetition_penalty),)
             uni = ws.get("gen_uniform", (max_new_tokens, Bn), F32)
             if do_sample and generator is not None and generator.device.type != uni.device.type:
                 uni.copy_(torch.rand(uni.shape, generator=generator))      # a host generator: draw there, same stream of uniforms

@@ -528,6 +528,13 @@ def test_generate_edge_cases(env):
         rt.generate([[[3, 4], speech_segment(0, 5)]], torch.zeros(1, 4, cfg.llama.hidden, device=DEV), max_new_tokens=T)
     with pytest.raises(ValueError, match="num_beams"):
         rt.generate(prompts[1:], None, max_new_tokens=T, num_beams=0)
+    with pytest.raises(ValueError, match="num_beams <= 8"):
+        rt.generate(prompts[1:], None, max_new_tokens=T, num_beams=9)
+    with pytest.raises(ValueError, match="max_new_tokens <= 64"):
+        rt.generate(prompts[1:], None, max_new_tokens=65, num_beams=2)
+    sampled = rt.generate(prompts[1:], None, max_new_tokens=2, do_sample=True, top_k=100000, top_p=0.9,
+                          generator=torch.Generator(device=DEV).manual_seed(1))      # HF clamps top_k to the vocabulary
+    assert sampled.tokens.shape[0] == 2
 
 
 def test_encode_speech_edge_lengths(env):
