@@ -122,3 +122,25 @@ def test_cli_qwen2_end_to_end(tmp_path):
     assert rc == 0
     res = [f for f in os.listdir(tmp_path) if f.endswith("_results.json")]
     assert len(res) == 1 and len(json.load(open(tmp_path / res[0]))) == 3
+
+
+def test_audio_longer_than_30_seconds_is_truncated_like_the_feature_extractor(model):
+    """WhisperFeatureExtractor (inside the reference's Qwen2-Audio processor, models/custom_qwen.py:57) cuts every clip to 30 s =
+    3000 mel frames = 750 audio tokens: a 31.5 s clip must expand to 750 placeholders and match the oracle on the first 30 s."""
+    from oracle import audio_frontend as af, models as om
+    enc, prompt_len, audios = _batch(model, secs=(31.5, 2.0))
+    mel_lens = enc.feature_attention_mask.sum(-1).tolist()
+    assert mel_lens[0] == 3000 and int((enc.input_ids[0] == model.cfg.audio_token_id).sum()) == 750 + ((200 - 1) // 2 + 1 - 2) // 2 + 1
+    feats, out_lens = model.runtime.encode_audio(input_features=enc.input_features, mel_lens=mel_lens)
+    raw, raw_lens = model.runtime.encode_audio(raw_wav=torch.nn.utils.rnn.pad_sequence([torch.from_numpy(a) for a in audios], batch_first=True),
+                                               wav_lens=[len(a) for a in audios])
+    assert out_lens == raw_lens == [750, 50]
+    sd = _oracle_sd(model)
+    spec = torch.stack([torch.from_numpy(af.whisper_logmel(a, n_mels=128)) for a in audios])
+    ref, ref_lens = om.qwen_audio_features(sd, spec, mel_lens, model.cfg.audio.n_heads, rnd=om.bf16_round)
+    assert ref_lens == out_lens
+    for i, n in enumerate(out_lens):
+        assert _rel(feats[i, :n], ref[i, :n]) < 1.5e-3 and _rel(raw[i, :n], ref[i, :n]) < 1.5e-3
+    batch = {"input_ids": enc.input_ids[:, :prompt_len], "attention_mask": enc.attention_mask[:, :prompt_len],
+             "input_features": enc.input_features, "feature_attention_mask": enc.feature_attention_mask}
+    assert len(model.generate_output(batch)) == 1
