@@ -116,6 +116,26 @@ def test_clips_longer_than_30_seconds_keep_their_extra_windows(model):
     short = _batch(model, "speech", n=2, bs=2, num_examples=1, secs=3.0, vary=False)
     short = {k: (v.to("cuda") if isinstance(v, torch.Tensor) else v) for k, v in short.items()}
     assert model.get_speech_embeddings(short)[0].shape[:2] == (2, 88)
+    # a 3 s clip collated with the 30.8 s one: the reference's BEATs sees BOTH at the collated width (padding mask), so the short
+    # row carries 90 tokens too — against the oracle on the padded waveform
+    from oracle import audio_frontend as af, models as om
+    mixed = {"raw_wav": torch.zeros(2, b["raw_wav"].shape[1]), "wav_lengths": torch.tensor([48000, int(b["wav_lengths"][0])]),
+             "prompt": b["prompt"], "num_examples": torch.zeros(2, dtype=torch.long)}
+    mixed["raw_wav"][0, :48000] = short["raw_wav"][0, :48000].cpu()
+    mixed["raw_wav"][1] = b["raw_wav"][0].cpu()
+    mixed["padding_mask"] = torch.arange(mixed["raw_wav"].shape[1])[None] >= mixed["wav_lengths"][:, None]
+    sp2 = model.get_speech_embeddings(dict(mixed))[0]
+    assert sp2.shape[:2] == (2, 90)
+    sd = {k: v.float().cpu() for k, v in model.salmonn.state_dict().items()}
+    cfg = model.cfg
+    for i in range(2):
+        n = int(mixed["wav_lengths"][i])
+        spec = torch.from_numpy(af.whisper_logmel(mixed["raw_wav"][i, :n].numpy()))[None]
+        ref = om.salmonn_encode_speech(sd, spec, mixed["raw_wav"][i:i + 1], [n], cfg.whisper.n_heads, rnd=om.bf16_round,
+                                       beats_cfg=dict(n_heads=cfg.beats.n_heads), qformer_heads=cfg.qformer.n_heads)
+        rel = float((sp2[i].cpu() - ref[0]).norm() / ref[0].norm())
+        print(f"collated width 30.8 s, row {i} ({n} valid samples): {ref.shape[1]} windows, rel {rel:.2e}")
+        assert ref.shape[1] == 90 and rel < 1.5e-3
 
 
 def test_get_speech_embeddings_matches_oracle_batch1(model):
