@@ -27,7 +27,7 @@ __device__ __forceinline__ void store4(void* base, int64_t off, int dtype, f32x4
 
 // One WAVE per row (4 rows per block): the row lives in registers, both statistics are shuffle-only
 // reductions — no LDS, no barrier.  MAXV = float4 chunks per lane (N <= 64*4*MAXV).
-template <bool RMS, int MAXV>
+template <bool RMS, int MAXV, bool HOIST>
 __global__ __launch_bounds__(NT) void norm_kernel(const void* x, int64_t ldx, const void* res,
                                                    float alpha, const float* gamma,
                                                    const float* beta, void* y, int64_t ldy,
@@ -53,6 +53,21 @@ __global__ __launch_bounds__(NT) void norm_kernel(const void* x, int64_t ldx, co
                : (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
     }
   }
+  // HOIST (launches of few rows): gamma / beta are loaded HERE, under the reductions.  Left inside the store loop below, each load
+  // waits behind the previous chunk's store (y may alias them as far as the compiler knows), i.e. 16 serialised L2 round trips
+  // per row — 12-13 us for the single-row launches of a small decode batch, where nothing else hides them.  Same values, same
+  // arithmetic, so the choice may depend on M; at large M the extra registers cost occupancy and bandwidth (measured, round 2).
+  f32x4 gv[HOIST ? MAXV : 1], bv[(HOIST && !RMS) ? MAXV : 1];
+  if (HOIST) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        gv[i] = *(const f32x4*)(gamma + c * 4);
+        if (!RMS) bv[i] = *(const f32x4*)(beta + c * 4);
+      }
+    }
+  }
   float mean = 0.f, rstd;
   if (RMS) {
     rstd = rsqrtf(wave_reduce_sum(s) / (float)N + eps);
@@ -76,12 +91,12 @@ __global__ __launch_bounds__(NT) void norm_kernel(const void* x, int64_t ldx, co
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
     if (c < nvec) {
-      const f32x4 g = *(const f32x4*)(gamma + c * 4);
+      const f32x4 g = HOIST ? gv[i] : *(const f32x4*)(gamma + c * 4);
       f32x4 o;
       if (RMS) {
         o = v[i] * rstd * g;
       } else {
-        const f32x4 b = *(const f32x4*)(beta + c * 4);
+        const f32x4 b = HOIST ? bv[i] : *(const f32x4*)(beta + c * 4);
         o = (v[i] - mean) * rstd * g + b;
       }
       store4(y, m * ldy + c * 4, out_dtype, o);
@@ -229,9 +244,17 @@ void launch_norm(hipStream_t st, const void* x, int64_t ldx, const void* res, fl
   }
   const dim3 grid((M + 3) / 4);
   const int per_lane = ((N >> 2) + 63) / 64;   // float4 chunks per lane; exact-fit instantiations keep VGPRs (and so occupancy) tight
-#define ICL_NORM_CASE(V)                                                                                             \
-  hipLaunchKernelGGL((norm_kernel<RMS, V>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, N, \
-                     eps, in_dtype, out_dtype)
+  const bool few_rows = M <= 2048;             // at most two workgroups per CU: latency, not bandwidth, is what the launch costs
+#define ICL_NORM_CASE(V)                                                                                                  \
+  do {                                                                                                                    \
+    constexpr bool CAN = V * (RMS ? 2 : 3) * 4 <= 200;      /* registers: row + gamma (+ beta) */                          \
+    if (CAN && few_rows)                                                                                                  \
+      hipLaunchKernelGGL((norm_kernel<RMS, V, CAN>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, M, \
+                         N, eps, in_dtype, out_dtype);                                                                    \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((norm_kernel<RMS, V, false>), grid, block, 0, st, x, ldx, res, alpha, gamma, beta, y, ldy, y2, ldy2, \
+                         M, N, eps, in_dtype, out_dtype);                                                                 \
+  } while (0)
   if (per_lane <= 3) ICL_NORM_CASE(3);         // N <= 768  (BEATs, Q-Former)
   else if (per_lane <= 5) ICL_NORM_CASE(5);    // N <= 1280 (Whisper)
   else if (per_lane <= 8) ICL_NORM_CASE(8);    // N <= 2048

@@ -414,6 +414,27 @@ def test_norm_streaming_variant(B, N, rms, in_dtype):
     assert (f32 - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("N", [768, 1280, 2048, 4096, 5120])
+@pytest.mark.parametrize("rms", [True, False])
+def test_norm_few_row_launches_round_like_large_ones(B, N, rms):
+    """Launches of few rows (a small decode batch: one to eight rows per call) load gamma / beta ahead of the reductions instead
+    of chunk by chunk; the arithmetic is the same, so a row is bit-identical whether it is normalised alone or among 4100."""
+    M = 4100
+    x = torch.randn(M, N, device=DEV) * 2 + 0.25
+    g, b = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        big = torch.empty(M, N, dtype=dt, device=DEV)
+        for rows in (1, 3, 8):
+            few = torch.empty(rows, N, dtype=dt, device=DEV)
+            if rms:
+                B.rmsnorm(x, g, big, 1e-5)
+                B.rmsnorm(x[100:100 + rows], g, few, 1e-5)
+            else:
+                B.layernorm(x, g, b, big, 1e-5)
+                B.layernorm(x[100:100 + rows], g, b, few, 1e-5)
+            assert torch.equal(few, big[100:100 + rows]), (N, rms, dt, rows)
+
+
 @pytest.mark.parametrize("N", [4096, 5120])
 def test_rmsnorm(B, N):
     M = 19
