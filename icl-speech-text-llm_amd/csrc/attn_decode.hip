@@ -11,7 +11,10 @@ namespace {
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;
 
-template <int D>
+// UNR = key rounds (4 * KPW keys each) whose K and V loads are issued before the first of them is consumed.  A stream's keys and
+// their order do not depend on it, so the result is bit-identical for any UNR: few workgroups (a small decode batch: one block
+// per (sequence, head), nothing else on the CU to hide a 2-3 us round trip per loop iteration) take 16, a full chip takes 4.
+template <int D, int UNR>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* Q, int64_t ldq,
                                                            const unsigned short* Kc, const unsigned short* Vc,
                                                            unsigned short* O, int64_t ldo, const int* lens,
@@ -41,7 +44,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const unsigned short* 
 #pragma unroll
   for (int t = 0; t < 8; ++t) o[t] = 0.f;
 
-  constexpr int UNR = 4;
   for (int j0 = wave * KPW; j0 < len; j0 += 4 * KPW * UNR) {
     u32x4 kr[UNR], vr[UNR];
 #pragma unroll
@@ -110,14 +112,17 @@ extern "C" int icl_attn_decode_bf16(const void* Q, int64_t ldq, const void* Kc, 
   ICL_CHECK_ARG(ldq % 8 == 0 && ((uintptr_t)Q & 15) == 0 && ((uintptr_t)Kc & 15) == 0 && ((uintptr_t)Vc & 15) == 0,
                 "icl_attn_decode_bf16: misaligned operands");
   dim3 grid(n_heads, n_seqs);
-  if (head_dim == 64)
-    hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)Q,
-                       ldq, (const unsigned short*)Kc, (const unsigned short*)Vc, (unsigned short*)O, ldo, lens,
-                       n_heads, max_len, scale * LOG2E);
-  else
-    hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)Q,
-                       ldq, (const unsigned short*)Kc, (const unsigned short*)Vc, (unsigned short*)O, ldo, lens,
-                       n_heads, max_len, scale * LOG2E);
+  const bool few = (int64_t)n_seqs * n_heads <= 1024;      // at most four workgroups per CU: latency-bound, not bandwidth-bound
+#define ICL_DECODE_CASE(DD, UU)                                                                                       \
+  hipLaunchKernelGGL((attn_decode_kernel<DD, UU>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)Q, ldq, \
+                     (const unsigned short*)Kc, (const unsigned short*)Vc, (unsigned short*)O, ldo, lens, n_heads, max_len, \
+                     scale * LOG2E)
+  if (head_dim == 64) {
+    if (few) ICL_DECODE_CASE(64, 16); else ICL_DECODE_CASE(64, 4);
+  } else {
+    if (few) ICL_DECODE_CASE(128, 16); else ICL_DECODE_CASE(128, 4);
+  }
+#undef ICL_DECODE_CASE
   ICL_CHECK_LAUNCH("icl_attn_decode_bf16");
   return ICL_OK;
 }

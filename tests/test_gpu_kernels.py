@@ -361,6 +361,24 @@ def test_attn_decode(B, D, H):
         assert (out[b].float() - ref).abs().max().item() <= 1e-2
 
 
+@pytest.mark.parametrize("D,H", [(128, 32), (64, 12)])
+def test_attn_decode_rounds_the_same_in_any_batch(B, D, H):
+    """Few workgroups (a small decode batch) issue 16 key rounds of loads at a time, a full chip 4: the keys of a lane's stream
+    and their order are the same, so a (sequence, head) gives bit-identical output alone and among 120 sequences."""
+    Bn, max_len = 120, 448
+    lens = torch.randint(1, max_len + 1, (Bn,), dtype=torch.int32)
+    lens[:4] = torch.tensor([1, 386, 448, 65], dtype=torch.int32)
+    lens = lens.to(DEV)
+    q = _rand_bf16(Bn, H * D, seed=51)
+    kc, vc = _rand_bf16(Bn, H, max_len, D, seed=52), _rand_bf16(Bn, H, max_len, D, seed=53)
+    big = torch.empty(Bn, H * D, dtype=torch.bfloat16, device=DEV)
+    B.attn_decode(q, kc, vc, big, lens, H, D, max_len, D ** -0.5)          # 120 * H > 1024 workgroups
+    for n in (1, 4):
+        few = torch.empty(n, H * D, dtype=torch.bfloat16, device=DEV)
+        B.attn_decode(q[:n], kc[:n], vc[:n], few, lens[:n], H, D, max_len, D ** -0.5)
+        assert torch.equal(few, big[:n])
+
+
 # ------------------------------------------------------------------------------------------------
 # norms / element-wise
 # ------------------------------------------------------------------------------------------------
