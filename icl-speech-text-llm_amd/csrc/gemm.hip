@@ -20,11 +20,17 @@ using namespace iclg;
 namespace {
 
 
-template <int WAVES_M, int WAVES_N, int MI, int NI>
+// NST = K-tiles of A and W resident in LDS per block.  2: the launch has blocks to spare and occupancy hides the load latency
+// (64x64: 32 KiB, five blocks per CU).  Deep (4 x 16 KiB for the 64x64 tile, 3 x 32 KiB for the 128x128 tile): every block of the
+// launch is resident at once and each keeps NST - 1 K-tiles of loads in flight.  Same MFMA sequence either way (bit-identical).
+#define TILE_STAGES_DEEP(BM_, BN_) (((BM_) + (BN_)) <= 128 ? 4 : 3)
+
+template <int WAVES_M, int WAVES_N, int MI, int NI, int NST>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   constexpr int BM = WAVES_M * MI * 16, BN = WAVES_N * NI * 16;
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
   constexpr int A_INSTR = BM / 32, W_INSTR = BN / 32;  // glds wave-instructions per wave
+  constexpr int G_STAGE = A_INSTR + W_INSTR;            // VMEM instructions per wave and K-tile
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -68,8 +74,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     gw[j] = p.W + (int64_t)gn * p.ldw + chunk * 8;
   }
 
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * BUF;
+  auto stage = [&](int buf_off, int kt) {      // buf_off: byte offset of the ring slot
+    char* base = smem + buf_off;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j)
       __builtin_amdgcn_global_load_lds((gptr_t)(ga[j] + (int64_t)kt * 64),
@@ -126,8 +132,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
   }
   if (kt0 < kt1) {
+    // NST-deep ring of K-tiles: NST - 1 tiles of LDS-DMA in flight while one is consumed, counted waits (loads past the end of
+    // the K range are clamped to its last tile so that the count is the same in every iteration), one barrier per K-tile.
+    // With two stages and a full drain per K-tile a block spent most of each tile waiting for its one load in flight: the
+    // launches that cannot fill the chip with blocks (prefill of a few sequences, BEATs / Q-Former shapes) were latency-bound.
     __builtin_amdgcn_sched_barrier(0);
-    stage(0, kt0);
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_) stage(s_ * BUF, min(kt0 + s_, kt1 - 1));
     __builtin_amdgcn_sched_barrier(0);
     if (fold_bias) {
 #pragma unroll
@@ -135,12 +146,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = acc[i][j] + bias_f[j];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
+    int cur = 0, fill = (NST - 1) * BUF;        // byte offsets: slot being consumed, slot to refill (= the one consumed last)
     for (int kt = kt0; kt < kt1; ++kt) {
-      if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
-      const char* a_s = smem + cur * BUF;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * G_STAGE) : "memory");   // K-tile kt has landed (this wave's part)
+      __syncthreads();                          // ... everyone's part; and everyone is done reading the buffer of K-tile kt-1
+      if (NST > 2) __builtin_amdgcn_sched_barrier(0);
+      if (NST > 2 || kt + 1 < kt1)              // two stages wait for vmcnt(0) anyway: no clamped over-issue needed there
+        stage(fill, min(kt + NST - 1, kt1 - 1));
+      const char* a_s = smem + cur;
       const char* w_s = a_s + A_BYTES;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -155,10 +168,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
           for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
+      fill = cur;
+      cur = cur == (NST - 1) * BUF ? 0 : cur + BUF;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped over-issue must not outlive the block's LDS
   }
 
   // ---- epilogue: acc[i][j][r] = C[m][n], m = m0 + wm*MI*16 + i*16 + fr, n = n0 + wn*NI*16 + j*16 + fq*4 + r ----
@@ -617,13 +630,11 @@ int launch_m128(GemmParams& p, hipStream_t stream) {
   return ICL_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int MI, int NI>
-int launch_tile(GemmParams& p, int batch, hipStream_t stream) {
+template <int WAVES_M, int WAVES_N, int MI, int NI, int NST>
+int launch_tile_n(GemmParams& p, dim3 grid, hipStream_t stream) {
   constexpr int BM = WAVES_M * MI * 16, BN = WAVES_N * NI * 16;
-  constexpr int SMEM = (BM + BN) * 128 * 2;
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  auto kern = gemm_bf16_kernel<WAVES_M, WAVES_N, MI, NI>;
+  constexpr int SMEM = (BM + BN) * 128 * NST;
+  auto kern = gemm_bf16_kernel<WAVES_M, WAVES_N, MI, NI, NST>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -633,10 +644,30 @@ int launch_tile(GemmParams& p, int batch, hipStream_t stream) {
     }
     attr_set = true;
   }
-  dim3 grid(p.tiles_m * p.tiles_n, 1, p.split_k > 1 ? p.split_k : batch);
   hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, stream, p);
   ICL_CHECK_LAUNCH("icl_gemm_bf16");
   return ICL_OK;
+}
+
+template <int WAVES_M, int WAVES_N, int MI, int NI>
+int launch_tile(GemmParams& p, int batch, hipStream_t stream) {
+  constexpr int BM = WAVES_M * MI * 16, BN = WAVES_N * NI * 16;
+  constexpr int DEEP = TILE_STAGES_DEEP(BM, BN);
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid(p.tiles_m * p.tiles_n, 1, p.split_k > 1 ? p.split_k : batch);
+  static int n_cu = 0;
+  if (n_cu <= 0) {
+    n_cu = icl_device_cu_count();
+    if (n_cu <= 0) n_cu = 256;
+  }
+  // deep ring only when ALL blocks of the launch fit on the chip at once at its LDS footprint (160 KiB per CU): measured on
+  // MI355X (tools/gemm_ab.py --shapes small): 384 blocks 35 -> 26 us, 480 blocks 43 -> 37 us; with blocks to spare the two-stage
+  // form's occupancy wins (1152 blocks: 61 us vs 86 us).  The choice does not change a bit of the result.
+  const int64_t blocks = (int64_t)grid.x * grid.z;
+  const int per_cu = (160 * 1024) / ((BM + BN) * 128 * DEEP);
+  if (blocks <= (int64_t)n_cu * per_cu) return launch_tile_n<WAVES_M, WAVES_N, MI, NI, DEEP>(p, grid, stream);
+  return launch_tile_n<WAVES_M, WAVES_N, MI, NI, 2>(p, grid, stream);
 }
 
 }  // namespace

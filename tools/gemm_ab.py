@@ -51,6 +51,16 @@ SHAPES = {
               ("ll o     res->f32", 48128, 4096, 4096, 0, 0, 1, 0, 1),
               ("ll gu    swiglu->bf16", 48128, 22016, 4096, 0, 0, 0, 1, 0),
               ("ll down  res->f32", 48128, 4096, 11008, 0, 0, 1, 0, 1)],
+    "small": [("pf1 qkv  ->bf16", 376, 12288, 4160, 0, 0, 0, 0, 0),      # prefill of ONE 376-position prompt (no fused RoPE here)
+              ("pf1 o    res->f32", 376, 4096, 4096, 0, 0, 1, 0, 1),
+              ("pf1 gu   swiglu->bf16", 376, 22016, 4096, 0, 0, 0, 1, 0),
+              ("pf1 down res->f32", 376, 4096, 11008, 0, 0, 1, 0, 1),
+              ("wh1 qkv  bias->bf16", 1500, 3840, 1280, 1, 0, 0, 0, 0),   # one 30 s clip
+              ("wh1 fc1  bias+gelu", 1500, 5120, 1280, 1, 1, 0, 0, 0),
+              ("wh1 fc2  bias+res->f32", 1500, 1280, 5120, 1, 0, 1, 0, 1),
+              ("be1 qkv  bias->bf16", 1496, 2304, 768, 1, 0, 0, 0, 0),
+              ("be1 fc2  bias->f32", 1496, 768, 3072, 1, 0, 0, 0, 1),
+              ("qf  kv   bias->bf16", 1500, 1536, 2048, 1, 0, 0, 0, 0)],
     "beats": [("be qkv   bias->bf16", 382976, 2304, 768, 1, 0, 0, 0, 0),
               ("be o     bias->f32", 382976, 768, 768, 1, 0, 0, 0, 1),
               ("be fc1   bias+gelu->bf16", 382976, 3072, 768, 1, 1, 0, 0, 0),
@@ -68,7 +78,7 @@ def run(lib, g):
 
 for fam in args.shapes.split(","):
     for (name, M, N, K, bias, gelu, res, swiglu, of32) in SHAPES[fam]:
-        M = int(M * args.scale_m) // 256 * 256 or 256
+        M = (int(M * args.scale_m) // 256 * 256 or 256) if fam != "small" else M
         torch.manual_seed(0)
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
@@ -87,7 +97,7 @@ for fam in args.shapes.split(","):
             g.M, g.N, g.K, g.batch = M, N, K, 1
             g.epilogue = (1 if bias else 0) | (2 if gelu else 0) | (4 if res else 0) | (8 if swiglu else 0)
             g.out_dtype = B.ICL_F32 if of32 else B.ICL_BF16
-            g.res_dtype, g.split_k, g.tile = B.ICL_F32, 1, 3
+            g.res_dtype, g.split_k, g.tile = B.ICL_F32, 1, (3 if fam != "small" else 0)
             gs.append(g)
         for (nm, lib), g in zip(libs, gs):          # warm-up + result check
             run(lib, g)
