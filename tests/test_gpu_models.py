@@ -317,6 +317,16 @@ def test_generate_sampled_and_penalised_greedy(env):
     other = rt.generate(prompts, None, max_new_tokens=8, do_sample=True, temperature=0.8, top_p=0.9, repetition_penalty=1.2,
                         generator=torch.Generator(device=DEV).manual_seed(99), suppress_eos=True).tokens
     assert not torch.equal(other, runs[0])
+    # two EOS ids in sample mode (Qwen2-Audio's generation_config: do_sample + [151645, 151643]): same draws, a row ends at the first
+    # occurrence of either id and is pad-filled
+    pair = (int(runs[0][0, 2]), int(runs[0][1, 4]))
+    stop = rt.generate(prompts, None, max_new_tokens=8, do_sample=True, temperature=0.8, top_p=0.9, top_k=50, repetition_penalty=1.2,
+                       generator=torch.Generator(device=DEV).manual_seed(1234), eos_id=pair, pad_id=cfg.llama.pad_id).tokens
+    for b in range(3):
+        want = runs[0][b].tolist()
+        cut = next((i for i, t in enumerate(want) if t in pair), None)
+        exp = want if cut is None else want[:cut + 1] + [cfg.llama.pad_id] * (len(want) - cut - 1)
+        assert stop[b].tolist() == exp[:stop.shape[1]], (b, stop[b].tolist(), exp)
     # (b) penalised greedy vs oracle
     pen = rt.generate(prompts, None, max_new_tokens=8, repetition_penalty=1.5, suppress_eos=True, want_first_logits=True)
     plain = rt.generate(prompts, None, max_new_tokens=8, suppress_eos=True)
