@@ -25,7 +25,7 @@ constexpr float BEAM_NEG = -1.0e9f;
 __device__ __forceinline__ bool lex_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
 __global__ __launch_bounds__(256) void beam_step_kernel(
-    const float* __restrict__ logits, int64_t ldl, int rows_per_batch, int V, int K, int T, int step, int eos_id, int eos_id2,
+    const float* __restrict__ logits, int64_t ldl, int rows_per_batch, int V, int K, int T, int step, int eos_id, int eos_id2, float rep_pen,
     float lenpen_next,   // (step + 1) ** length_penalty: divides a hypothesis finishing now AND the best running score after it
     float* __restrict__ run_score, int* __restrict__ run_seq, float* __restrict__ fin_score, int* __restrict__ fin_seq,
     int* __restrict__ fin_len, int* __restrict__ fin_flag, int* __restrict__ unsat, int* __restrict__ next_ids,
@@ -72,6 +72,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
     s_old_run[i] = run_seq[(int64_t)b * K * T + i];
     s_old_fin[i] = fin_seq[(int64_t)b * K * T + i];
   }
+  __syncthreads();
+  const bool penalised = rep_pen != 1.0f && step > 0;      // HF's RepetitionPenaltyLogitsProcessor, applied to the log-probabilities
 
   // ---- the NC best continuations, best first -------------------------------------------------------------------------
   float pv = INFINITY;
@@ -83,7 +85,13 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
       const float m = s_m[k], ls = s_ls[k], rs = s_rs[k];
       const float* x = lbase + k * lstep;
       for (int v = tid; v < V; v += 256) {
-        const float a = ((x[v] - m) - ls) + rs;
+        float lp = (x[v] - m) - ls;
+        if (penalised) {                                   // tokens of beam k's own sequence: x < 0 ? x * penalty : x / penalty
+          bool seen = false;
+          for (int t = 0; t < step; ++t) seen = seen || s_old_run[k * T + t] == v;
+          if (seen) lp = lp < 0.f ? lp * rep_pen : lp / rep_pen;
+        }
+        const float a = lp + rs;
         const int idx = k * V + v;
         if ((a < pv || (a == pv && idx > pi)) && lex_better(a, idx, bv, bi)) {
           bv = a;
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void kv_copy_spans_kernel(
 
 extern "C" int icl_beam_step(const float* logits, int64_t ldl, int32_t rows_per_batch, int32_t B, int32_t V, int32_t num_beams,
                              int32_t max_new_tokens, int32_t step, int32_t eos_id, int32_t eos_id2, float length_penalty,
-                             float* run_score,
+                             float repetition_penalty, float* run_score,
                              int32_t* run_seq, float* fin_score, int32_t* fin_seq, int32_t* fin_len, int32_t* fin_flag,
                              int32_t* unsat, int32_t* next_ids, int32_t* parent, void* stream) {
   ICL_CHECK_ARG(logits && run_score && run_seq && fin_score && fin_seq && fin_len && fin_flag && unsat && next_ids && parent,
@@ -233,6 +241,7 @@ extern "C" int icl_beam_step(const float* logits, int64_t ldl, int32_t rows_per_
   ICL_CHECK_ARG(num_beams >= 1 && num_beams <= BEAM_MAX, "icl_beam_step: num_beams=%d must be in [1,%d]", num_beams, BEAM_MAX);
   ICL_CHECK_ARG(V >= (eos_id2 >= 0 ? 3 : 2) * num_beams, "icl_beam_step: V=%d < %d * num_beams", V, eos_id2 >= 0 ? 3 : 2);
   ICL_CHECK_ARG(eos_id2 < 0 || eos_id >= 0, "icl_beam_step: eos_id2 without eos_id");
+  ICL_CHECK_ARG(repetition_penalty > 0.0f, "icl_beam_step: repetition_penalty must be > 0");
   ICL_CHECK_ARG(max_new_tokens >= 1 && max_new_tokens <= BEAM_TMAX, "icl_beam_step: max_new_tokens=%d must be in [1,%d]",
                 max_new_tokens, BEAM_TMAX);
   ICL_CHECK_ARG(step >= 0 && step < max_new_tokens, "icl_beam_step: step=%d outside [0,%d)", step, max_new_tokens);
@@ -241,7 +250,7 @@ extern "C" int icl_beam_step(const float* logits, int64_t ldl, int32_t rows_per_
   // python: (cur_len + 1 - prompt_len) ** length_penalty in double, then the f32 tensor is divided by it
   const float lenpen = (float)pow((double)(step + 1), (double)length_penalty);
   hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, rows_per_batch, V, num_beams,
-                     max_new_tokens, step, eos_id, eos_id2, lenpen, run_score, run_seq, fin_score, fin_seq, fin_len, fin_flag, unsat,
+                     max_new_tokens, step, eos_id, eos_id2, repetition_penalty, lenpen, run_score, run_seq, fin_score, fin_seq, fin_len, fin_flag, unsat,
                      next_ids, parent);
   ICL_CHECK_LAUNCH("icl_beam_step");
   return ICL_OK;

@@ -18,7 +18,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libicl_hip.so"))
 
 ICL_BF16, ICL_F32 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 1, 2, 4, 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
@@ -79,7 +79,7 @@ _SIGNATURES = {
     "icl_sample_eos": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int32,
                                c_float, c_float, c_int32, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
-    "icl_beam_step": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
+    "icl_beam_step": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "icl_kv_copy_spans_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -406,7 +406,7 @@ class BeamState:
         self.unsat.fill_(1)
 
 
-def beam_step(logits, state: BeamState, step: int, eos_id, length_penalty: float, V=None):
+def beam_step(logits, state: BeamState, step: int, eos_id, length_penalty: float, V=None, repetition_penalty: float = 1.0):
     """One beam-search step over ``logits`` f32 [B, V] (step 0: the prompt's distribution, shared by the K beams) or
     [B * K, V] (row b * K + k = running beam k of row b)."""
     _require_gpu(logits, state.run_score)
@@ -416,7 +416,8 @@ def beam_step(logits, state: BeamState, step: int, eos_id, length_penalty: float
     e1, e2 = _eos_pair(eos_id)
     _check(load_library().icl_beam_step(logits.data_ptr(), logits.stride(0), rows, state.B,
                                         logits.shape[1] if V is None else V, state.K, state.T, step, e1, e2,
-                                        float(length_penalty), state.run_score.data_ptr(), state.run_seq.data_ptr(),
+                                        float(length_penalty), float(repetition_penalty), state.run_score.data_ptr(),
+                                        state.run_seq.data_ptr(),
                                         state.fin_score.data_ptr(), state.fin_seq.data_ptr(), state.fin_len.data_ptr(),
                                         state.fin_flag.data_ptr(), state.unsat.data_ptr(), state.next_ids.data_ptr(),
                                         state.parent.data_ptr(), _stream()), "icl_beam_step")

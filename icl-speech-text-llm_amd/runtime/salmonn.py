@@ -181,12 +181,13 @@ class CausalLMRuntimeMixin:
         if num_beams != 1:
             if num_beams < 1:
                 raise ValueError(f"num_beams must be >= 1, not {num_beams}")
-            if do_sample or repetition_penalty != 1.0 or want_step_logits:
-                raise NotImplementedError("beam search runs without sampling, repetition penalty or a per-step logits trace")
+            if do_sample or want_step_logits:
+                raise NotImplementedError("beam search runs without sampling (HF's beam-sample mode) and without a per-step logits trace")
             if num_beams > 8 or max_new_tokens > 64:      # the step kernel's state (include/icl_hip.h); refused before any launch
                 raise ValueError(f"beam search supports num_beams <= 8 and max_new_tokens <= 64 (got {num_beams}, {max_new_tokens})")
             return self._generate_beam(prompts, speech, max_new_tokens, eos, pad, num_beams, float(length_penalty),
-                                       want_first_logits, cache_len_multiple, debug=beam_debug)
+                                       want_first_logits, cache_len_multiple, debug=beam_debug,
+                                       repetition_penalty=float(repetition_penalty))
         h, lens = self.embed_prompts(prompts, speech)
         Bn = len(lens)
         need = max(lens) + max_new_tokens
@@ -308,7 +309,8 @@ class CausalLMRuntimeMixin:
     beam_rows = 256            # decode rows (sequences x beams) per pass of beam search: the widest decode tile
 
     def _generate_beam(self, prompts, speech, max_new_tokens: int, eos: int, pad: int, K: int, length_penalty: float,
-                       want_first_logits: bool, cache_len_multiple: int, debug: Optional[dict] = None) -> GenerateResult:
+                       want_first_logits: bool, cache_len_multiple: int, debug: Optional[dict] = None,
+                       repetition_penalty: float = 1.0) -> GenerateResult:
         """HF beam search with ``inputs_embeds`` only (models/custom_salmon.py:704-715; transformers `_beam_search`,
         early_stopping=False).  The prompt is prefilled ONCE per row (HF prefills K copies), its K/V rows are copied to the
         row's K beams, and every step is `icl_beam_step` (log-softmax, the 2K best continuations, running / finished
@@ -324,7 +326,8 @@ class CausalLMRuntimeMixin:
         if n_rows > per_pass:                                  # rows x beams beyond the decode tile: run the rows in groups
             assert debug is None
             parts = [self._generate_beam(prompts[i:i + per_pass], speech, max_new_tokens, eos, pad, K, length_penalty,
-                                         want_first_logits, cache_len_multiple) for i in range(0, n_rows, per_pass)]
+                                         want_first_logits, cache_len_multiple, repetition_penalty=repetition_penalty)
+                     for i in range(0, n_rows, per_pass)]
             width = max(p.tokens.shape[1] for p in parts)
             toks = torch.full((n_rows, width), pad, dtype=torch.int64)
             r = 0
@@ -358,7 +361,7 @@ class CausalLMRuntimeMixin:
         st = B.BeamState(ws.get, Bn, K, T, pad)
 
         def score(lg, step):
-            B.beam_step(lg, st, step, eos, length_penalty, V=c.vocab)
+            B.beam_step(lg, st, step, eos, length_penalty, V=c.vocab, repetition_penalty=repetition_penalty)
             if debug is not None:
                 for key, val in (("logits", lg), ("run_seq", st.run_seq), ("parent", st.parent), ("next", st.next_ids),
                                  ("fin_seq", st.fin_seq), ("fin_score", st.fin_score), ("fin_len", st.fin_len)):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICL_ABI_VERSION 3
+#define ICL_ABI_VERSION 4
 
 /* error codes */
 #define ICL_OK 0
@@ -333,6 +333,8 @@ int icl_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, fl
  *   {old finished slots, first-K continuations that stop, scored sum / (step+1)**length_penalty}, taken only while unsat[b];
  *   unsat[b] &= (run_score[b][0] / (step+1)**length_penalty beats the worst finished slot, or a slot is still empty).
  *   next_ids[b*K+i] / parent[b*K+i] = token and absolute source row (b*K + parent beam) of running beam i.
+ *   repetition_penalty != 1: the log-probability x of every token already in running beam k's sequence becomes x < 0 ? x * p : x / p
+ *   before run_score is added (HF applies RepetitionPenaltyLogitsProcessor after log_softmax in beam search).
  *   Initial state: run_score = {0, -1e9, ...}, fin_score = -1e9, fin_flag = fin_len = 0, unsat = 1, sequences = pad.
  *   The answer after T steps is fin_seq[b][0][0 .. fin_len[b][0]).
  *   Replaces HF GenerationMixin._beam_search (early_stopping=False, do_sample=False) behind generate(inputs_embeds=...,
@@ -343,7 +345,8 @@ int icl_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, fl
  *   cache.reorder_cache(beam_idx): only the positions after the prompt differ between the beams of a row.
  */
 int icl_beam_step(const float* logits, int64_t ldl, int32_t rows_per_batch, int32_t B, int32_t V, int32_t num_beams,
-                  int32_t max_new_tokens, int32_t step, int32_t eos_id, int32_t eos_id2, float length_penalty, float* run_score,
+                  int32_t max_new_tokens, int32_t step, int32_t eos_id, int32_t eos_id2, float length_penalty,
+                  float repetition_penalty, float* run_score,
                   int32_t* run_seq, float* fin_score, int32_t* fin_seq, int32_t* fin_len, int32_t* fin_flag,
                   int32_t* unsat, int32_t* next_ids, int32_t* parent, void* stream);
 int icl_kv_copy_spans_bf16(const void* src, void* dst, int64_t src_layer_stride, int64_t src_seq_stride,

@@ -419,7 +419,7 @@ class LlamaOracle:
         return (ids, first) if return_first_logits else ids
 
     def generate_beam(self, inputs_embeds: Tensor, max_new_tokens: int, eos_id: int, pad_id: int, num_beams: int,
-                      length_penalty: float = 1.0, return_scores: bool = False):
+                      length_penalty: float = 1.0, return_scores: bool = False, repetition_penalty: float = 1.0):
         """HF beam search as ``generate(inputs_embeds=..., num_beams=K, length_penalty=...)`` runs it for
         models/custom_salmon.py:704-715 / models/multi_task_model.py:142 (bookkeeping: ``BeamBookkeeping``).  Returns the best
         finished hypothesis per row [B, width] padded with ``pad_id`` (width = longest returned)."""
@@ -430,7 +430,7 @@ class LlamaOracle:
         lg = self.logits(h[:, -1:])[:, 0]                                             # [B, V]
         cache = [(k.repeat_interleave(K, 0), v.repeat_interleave(K, 0)) for k, v in cache]
         lg = lg.repeat_interleave(K, 0)                                               # beam-major rows: b * K + k
-        bk = BeamBookkeeping(Bn, K, max_new_tokens, eos_id, length_penalty)
+        bk = BeamBookkeeping(Bn, K, max_new_tokens, eos_id, length_penalty, repetition_penalty)
         for step in range(max_new_tokens):
             parents, toks = bk.step(lg)
             if bk.done:
@@ -505,8 +505,9 @@ class BeamBookkeeping:
         finished slot (all K slots filled);
       * the search ends when every row is closed or every continuation stopped (length limit)."""
 
-    def __init__(self, Bn: int, K: int, max_new_tokens: int, eos_id, length_penalty: float):
+    def __init__(self, Bn: int, K: int, max_new_tokens: int, eos_id, length_penalty: float, repetition_penalty: float = 1.0):
         self.Bn, self.K, self.T, self.eos, self.lp = Bn, K, max_new_tokens, _eos_set(eos_id), length_penalty
+        self.rep = float(repetition_penalty)
         self.keep = max(2, 1 + len(self.eos)) * K           # continuations kept per row: (1 + number of EOS ids) * K, at least 2K
         self.neg = torch.tensor(-1.0e9, dtype=torch.float32)
         self.run_seq = [[[] for _ in range(K)] for _ in range(Bn)]
@@ -522,6 +523,13 @@ class BeamBookkeeping:
         Bn, K, NEG, step = self.Bn, self.K, self.neg, self.t
         V = lg.shape[-1]
         logp = F.log_softmax(lg.float(), dim=-1).view(Bn, K, V)
+        if self.rep != 1.0:      # RepetitionPenaltyLogitsProcessor on the LOG-PROBABILITIES of each beam's own tokens (HF applies the
+            logp = logp.clone()  # processors after log_softmax in beam search): x < 0 ? x * penalty : x / penalty
+            for b in range(Bn):
+                for k in range(K):
+                    for t in set(self.run_seq[b][k]):
+                        x = logp[b, k, t]
+                        logp[b, k, t] = x * self.rep if x < 0 else x / self.rep
         acc = (logp + self.run_score[:, :, None]).view(Bn, K * V)
         top_v, top_i = torch.sort(acc, dim=1, descending=True, stable=True)      # torch.topk, with ties to the lower beam*V + token
         top_v, top_i = top_v[:, : self.keep], top_i[:, : self.keep]

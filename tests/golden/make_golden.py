@@ -739,6 +739,14 @@ def g16_beam_search():
         g2 = m.generate(inputs_embeds=emb, attention_mask=att, max_new_tokens=10, do_sample=False, num_beams=1, min_length=1,
                         pad_token_id=259, eos_token_id=[int(free[0, 3]), 221])      # 221: row 1's first greedy token
     out["two_eos_greedy_seq"], out["two_eos_greedy_eos"] = g2, np.array([int(free[0, 3]), 221])
+    # beams under a repetition penalty (custom_salmon.py:713 forwards it next to num_beams): the processor acts on log-probabilities
+    for name, nb, lp, pen, eos in (("rep3", 3, 1.0, 1.5, None), ("rep4_eos", 4, 1.0, 1.3, int(free[0, 3])), ("rep2_lp2", 2, 2.0, 2.0, None)):
+        with torch.no_grad():
+            r = m.generate(inputs_embeds=emb, attention_mask=att, max_new_tokens=10, do_sample=False, num_beams=nb, min_length=1,
+                           length_penalty=lp, repetition_penalty=pen, pad_token_id=259, eos_token_id=eos,
+                           return_dict_in_generate=True, output_scores=True)
+        out[name + "_seq"], out[name + "_score"] = r.sequences, r.sequences_scores
+        out[name + "_knobs"] = np.array([nb, lp, -1 if eos is None else eos, 10, -1, pen], dtype=np.float64)
     save("beam_tiny.npz", **out)
 
 

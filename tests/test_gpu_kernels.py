@@ -914,7 +914,8 @@ def test_sample_eos_matches_oracle_and_hf_golden():
 @pytest.mark.parametrize("Bn,K,V,T,lp,eos", [(3, 4, 260, 6, 1.0, 17), (2, 8, 32001, 5, 2.0, 2), (5, 1, 40, 4, 0.0, 3),
                                               (2, 3, 1000, 64, -1.0, 5), (1, 2, 4, 3, 1.0, 0), (3, 4, 300, 6, 1.0, (17, 40)),
                                               (2, 8, 32001, 4, -1.0, (2, 31999)), (2, 2, 6, 3, 1.0, (0, 5))])
-def test_beam_step_matches_oracle_scorer(B, Bn, K, V, T, lp, eos):
+@pytest.mark.parametrize("pen", [1.0, 1.6])
+def test_beam_step_matches_oracle_scorer(B, Bn, K, V, T, lp, eos, pen):
     """Scores: f32 log-softmax over up to 32001 columns summed in another order than torch (2e-5 relative).
     A whole search on synthetic logits that depend on each beam's history (a tiny recurrent stand-in for the decoder, advanced
     along the chosen parents): `icl_beam_step` and oracle.BeamBookkeeping must choose the same parents / tokens at every step and
@@ -928,7 +929,7 @@ def test_beam_step_matches_oracle_scorer(B, Bn, K, V, T, lp, eos):
     U[:, list(eos) if isinstance(eos, tuple) else eos] += 0.8     # EOS is a frequent contender (a tuple: HF's list of EOS ids, 3K kept)
     h = torch.randn(Bn, Hd, generator=g)
     state = B.BeamState(lambda name, shape, dt: torch.empty(shape, dtype=dt, device=DEV), Bn, K, T, pad_id=V - 1)
-    bk = om.BeamBookkeeping(Bn, K, T, eos, lp)
+    bk = om.BeamBookkeeping(Bn, K, T, eos, lp, pen)
 
     def logits_of(hid):
         lg = (hid @ U).float()
@@ -938,7 +939,7 @@ def test_beam_step_matches_oracle_scorer(B, Bn, K, V, T, lp, eos):
     hid = h
     lg = logits_of(hid)                                 # step 0: one distribution per row
     for s in range(T):
-        B.beam_step(lg.to(DEV), state, s, eos, lp)
+        B.beam_step(lg.to(DEV), state, s, eos, lp, repetition_penalty=pen)
         lg_bk = lg if lg.shape[0] == Bn * K else lg.repeat_interleave(K, 0)
         was_open = list(bk.open)
         parents, toks = bk.step(lg_bk)

@@ -409,10 +409,10 @@ def test_workspace_stays_bounded_over_ragged_batches(env):
     assert torch.equal(rt.encode_speech(probe_wav, [30000, 47000]), want_emb)
 
 
-def _beam_replay(dbg, Bn, K, T, eos, lp, pad):
+def _beam_replay(dbg, Bn, K, T, eos, lp, pad, pen=1.0):
     """The oracle's scorer driven by the logits the GPU search itself scored, step by step."""
     from oracle import models as om
-    bk = om.BeamBookkeeping(Bn, K, T, eos, lp)
+    bk = om.BeamBookkeeping(Bn, K, T, eos, lp, pen)
     steps = []
     for s, lg in enumerate(dbg["logits"]):
         lg = lg.cpu()
@@ -427,7 +427,8 @@ def _beam_replay(dbg, Bn, K, T, eos, lp, pad):
 
 @pytest.mark.parametrize("K,lp,eos_from", [(3, 1.0, None), (4, 1.0, (0, 2)), (2, 0.0, (1, 1)), (4, 2.0, (2, 3)), (3, -1.0, (0, 1)),
                                            (1, 1.0, None), (3, 1.0, ((0, 2), (1, 1))), (2, -1.0, ((2, 1), (0, 3)))])
-def test_beam_search_matches_oracle(env, K, lp, eos_from):
+@pytest.mark.parametrize("pen", [1.0, 1.4])
+def test_beam_search_matches_oracle(env, K, lp, eos_from, pen):
     """num_beams > 1 (models/custom_salmon.py:709-714 -> HF _beam_search).  Three checks on ragged prompts:
     (1) the oracle's scorer replayed on the logits the GPU search scored reproduces the GPU's choices at every step (parents,
         tokens) and its answer — the device bookkeeping is HF's;
@@ -442,21 +443,21 @@ def test_beam_search_matches_oracle(env, K, lp, eos_from):
     pad = cfg.llama.pad_id
     eos = -1
     if eos_from is not None:            # an EOS some hypothesis meets: the token the unconstrained search puts at (row, step)
-        free = rt.generate(prompts, None, max_new_tokens=T, suppress_eos=True, num_beams=K, length_penalty=lp)
+        free = rt.generate(prompts, None, max_new_tokens=T, suppress_eos=True, num_beams=K, length_penalty=lp, repetition_penalty=pen)
         if isinstance(eos_from[0], tuple):          # two EOS ids (HF's list form): 3K continuations per row
             eos = tuple(int(free.tokens[r, t]) for r, t in eos_from)
         else:
             eos = int(free.tokens[eos_from[0], eos_from[1]])
     dbg = {}
     if K == 1:                          # generate() sends one beam down the greedy path; the beam machinery must agree with it
-        res = rt._generate_beam(prompts, None, T, eos, pad, 1, lp, True, 64, debug=dbg)
+        res = rt._generate_beam(prompts, None, T, eos, pad, 1, lp, True, 64, debug=dbg, repetition_penalty=pen)
     else:
         res = rt.generate(prompts, None, max_new_tokens=T, eos_id=eos, pad_id=pad, num_beams=K, length_penalty=lp,
-                          want_first_logits=True, beam_debug=dbg, suppress_eos=eos == -1)
+                          want_first_logits=True, beam_debug=dbg, suppress_eos=eos == -1, repetition_penalty=pen)
     Bn = len(lens)
     assert len(dbg["logits"]) == T and dbg["logits"][0].shape[0] == Bn and dbg["logits"][1].shape[0] == Bn * K
     # (1) bookkeeping replay
-    bk, steps = _beam_replay(dbg, Bn, K, T, eos, lp, pad)
+    bk, steps = _beam_replay(dbg, Bn, K, T, eos, lp, pad, pen)
     for s, (parents, toks) in enumerate(steps):
         got_par, got_tok = dbg["parent"][s].cpu().long(), dbg["next"][s].cpu().long()
         if s + 1 < T:                           # at the length limit every continuation stops: the running order is arbitrary
@@ -482,12 +483,12 @@ def test_beam_search_matches_oracle(env, K, lp, eos_from):
     embs = [ob.embed(torch.tensor(p[0]))[None] for p in prompts]
     same = 0
     for b, e in enumerate(embs):
-        ids = ob.generate_beam(e, T, eos, pad, K, lp)[0].tolist()
+        ids = ob.generate_beam(e, T, eos, pad, K, lp, repetition_penalty=pen)[0].tolist()
         g = res.tokens[b].tolist()
         g = g[:len(ids)] if all(t == pad for t in g[len(ids):]) else g
         same += int(g == ids)
     print(f"free-running oracle agrees on {same}/{Bn} rows")
-    if K == 1:      # one beam is greedy search (HF's own equivalence): the GPU's greedy path must give the same ids
+    if K == 1 and pen == 1.0:      # one beam is greedy search (HF's own equivalence): the GPU's greedy path must give the same ids
         greedy = rt.generate(prompts, None, max_new_tokens=T, eos_id=eos, pad_id=pad, suppress_eos=eos == -1)
         assert greedy.tokens.tolist() == res.tokens.tolist()
 
@@ -506,6 +507,7 @@ def test_beam_search_in_row_groups_matches_one_pass(env):
     assert grouped.tokens.tolist() == one.tokens.tolist() and grouped.first_logits.shape[0] == 5
     with pytest.raises(NotImplementedError):
         rt.generate(prompts, None, max_new_tokens=5, num_beams=3, do_sample=True)
+    assert rt.generate(prompts, None, max_new_tokens=5, suppress_eos=True, num_beams=3, repetition_penalty=1.3).tokens.shape == (5, 5)
 
 
 def test_generate_edge_cases(env):

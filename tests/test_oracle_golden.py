@@ -77,7 +77,7 @@ def test_llama_forward_loss_and_generate_match_hf():
 
 
 BEAM_CASES = ["free4", "free3_lp2", "free2_lp0", "eos_mid4", "eos_first4", "eos_mid4_lpneg", "eos_mid5_lp2", "one_row_eos3",
-              "short3", "two_eos4", "two_eos2_lpneg", "two_eos3_lp2"]
+              "short3", "two_eos4", "two_eos2_lpneg", "two_eos3_lp2", "rep3", "rep4_eos", "rep2_lp2"]
 
 
 @pytest.mark.parametrize("case", BEAM_CASES)
@@ -90,12 +90,14 @@ def test_beam_search_matches_hf(case):
     llm = om.LlamaOracle(sd, n_heads=2, rms_eps=1e-5)
     emb = torch.from_numpy(a["emb"])
     K, lp, eos, max_new = g[case + "_knobs"][:4]
-    if len(g[case + "_knobs"]) > 4:                # HF's list form of eos_token_id
-        eos = [int(eos), int(g[case + "_knobs"][4])]
+    kn = g[case + "_knobs"]
+    if len(kn) > 4 and kn[4] >= 0:                 # HF's list form of eos_token_id
+        eos = [int(eos), int(kn[4])]
+    pen = float(kn[5]) if len(kn) > 5 else 1.0
     want = g[case + "_seq"]
     e = emb[1:] if want.shape[0] == 1 else emb
     ids, score = llm.generate_beam(e, int(max_new), eos_id=eos if isinstance(eos, list) else int(eos), pad_id=259, num_beams=int(K), length_penalty=float(lp),
-                                   return_scores=True)
+                                   return_scores=True, repetition_penalty=pen)
     assert ids.tolist() == want.tolist()
     assert np.abs(score.numpy() - g[case + "_score"]).max() < 2e-4 * max(1.0, float(np.abs(g[case + "_score"]).max()))
 
