@@ -750,6 +750,62 @@ def g16_beam_search():
     save("beam_tiny.npz", **out)
 
 
+def g17_multi_task_wrapper():
+    """The reference's MultiTaskModel wrapper logic (models/multi_task_model.py:52-149), imported unmodified over the stub SALMONN, with
+    the inner model's forward / generate_output replaced by recorders: task switching, prompt-template substitution, per-task knobs."""
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    llama, tok = _tiny_llama(seed=4), ByteTokenizer(260)
+
+    class StubSALMONN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.llama_model, self.llama_tokenizer = llama, tok
+
+        @classmethod
+        def from_config(cls, cfg):
+            return cls()
+
+    for name in ("SALMONN", "SALMONN.models", "SALMONN.models.salmonn_org"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["SALMONN.models.salmonn_org"].SALMONN = StubSALMONN
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from models.multi_task_model import MultiTaskModel as RefMT
+    tasks = {"sentiment": {"prompt_template": "SENTIMENT> ", "max_new_tokens": 4, "num_beams": 3},
+             "intent": {"prompt_template": "INTENT> ", "do_sample": True, "temperature": 0.5},
+             "plain": {"max_new_tokens": 7}}
+    mt = RefMT("salmonn", task_configs=tasks, default_task="intent", lora=False, device=torch.device("cpu"))
+    mt.model.prompt_template = "BASE: "
+    mt.model.batch_counter = 1
+    seen = {}
+    mt.model.forward = lambda samples: (seen.__setitem__("fwd", {k: (list(v) if isinstance(v, list) else v) for k, v in samples.items()}) or {"loss": 0.0})
+    mt.model.generate_output = lambda samples: (seen.__setitem__("gen", dict(samples)) or ["out"] * len(samples["prompt"]))
+    out = {"templates": {t: mt.get_task_prompt_template(t) for t in ("sentiment", "intent", "plain", "unknown")},
+           "template_current": mt.get_task_prompt_template(), "set_task": {}}
+    for t in ("sentiment", "nope", "plain"):
+        out["set_task"][t] = [mt.set_task(t), mt.current_task]
+    prompts = ["BASE: classify this", "BASE: and this BASE: twice", "no base here", "BASE: last"]
+    r = mt.forward({"prompt": list(prompts), "task": ["sentiment", None, "intent", "plain"]})
+    out["forward_with_tasks"] = {"prompts": seen["fwd"]["prompt"], "task_out": r["task"]}
+    r = mt.forward({"prompt": list(prompts)})
+    out["forward_without_tasks"] = {"prompts": seen["fwd"]["prompt"], "task_out": r["task"]}
+    r = mt.forward({"prompt": list(prompts[:2]), "task": [None, None]})
+    out["forward_all_none"] = {"prompts": seen["fwd"]["prompt"], "task_out": r["task"]}
+    gen = {}
+    for name, samples in (("task_sentiment", {"prompt": ["p"], "task": ["sentiment"]}),
+                          ("task_intent_overrides_batch_keys", {"prompt": ["p", "q"], "task": ["intent", "sentiment"], "max_new_tokens": 99}),
+                          ("task_plain", {"prompt": ["p"], "task": ["plain"]}),
+                          ("task_unknown", {"prompt": ["p"], "task": ["unknown"], "temperature": 0.3}),
+                          ("task_none", {"prompt": ["p"], "task": [None]}),
+                          ("no_task_key", {"prompt": ["p"]})):
+        res = mt.generate_output(samples)
+        gen[name] = {"samples_after": {k: v for k, v in seen["gen"].items() if k != "prompt"}, "current_task": mt.current_task, "n_out": len(res)}
+    out["generate_output"] = gen
+    with open(os.path.join(HERE, "multi_task_wrapper.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("multi_task_wrapper.json written")
+
+
 def g15_boundary():
     """The plugin boundary as the reference declares it: inspect.signature of BaseModel's public methods,
     ModelFactory's static methods, CustomSALMONN / CustomQwen constructors and entry points, and the action table of the
@@ -832,3 +888,4 @@ if __name__ == "__main__":
     g14_reference_glue_sentencepiece()
     g15_boundary()
     g16_beam_search()
+    g17_multi_task_wrapper()

@@ -653,3 +653,41 @@ def test_qwen_generation_config_json_is_inherited(tmp_path):
     assert _eos_pair(2) == (2, -1) and _eos_pair([151645, 151643]) == (151645, 151643) and _eos_pair((7, 7)) == (7, -1)
     with pytest.raises(ValueError):
         _eos_pair([1, 2, 3])
+
+
+def test_multi_task_wrapper_matches_the_reference():
+    """models/multi_task_model.py:52-149 — task switching, prompt-template substitution and per-task generation knobs — against
+    tests/golden/multi_task_wrapper.json, recorded from the reference's own MultiTaskModel (imported over a stub SALMONN) with the
+    inner model's forward / generate_output replaced by recorders, as here."""
+    from icl_speech_text_llm_amd.models.multi_task_model import MultiTaskModel
+    with open(os.path.join(os.path.dirname(__file__), "golden", "multi_task_wrapper.json")) as f:
+        want = json.load(f)
+    tasks = {"sentiment": {"prompt_template": "SENTIMENT> ", "max_new_tokens": 4, "num_beams": 3},
+             "intent": {"prompt_template": "INTENT> ", "do_sample": True, "temperature": 0.5},
+             "plain": {"max_new_tokens": 7}}
+    mt = MultiTaskModel("salmonn", task_configs=tasks, default_task="intent", arch="tiny", llama_path="none", device="cpu")
+    mt.model.prompt_template = "BASE: "
+    mt.model.batch_counter = 1
+    seen = {}
+    mt.model.forward = lambda samples: (seen.__setitem__("fwd", {k: (list(v) if isinstance(v, list) else v) for k, v in samples.items()}) or {"loss": 0.0})
+    mt.model.generate_output = lambda samples: (seen.__setitem__("gen", dict(samples)) or ["out"] * len(samples["prompt"]))
+    assert {t: mt.get_task_prompt_template(t) for t in ("sentiment", "intent", "plain", "unknown")} == want["templates"]
+    assert mt.get_task_prompt_template() == want["template_current"]
+    for t in ("sentiment", "nope", "plain"):
+        assert [mt.set_task(t), mt.current_task] == want["set_task"][t]
+    prompts = ["BASE: classify this", "BASE: and this BASE: twice", "no base here", "BASE: last"]
+    r = mt.forward({"prompt": list(prompts), "task": ["sentiment", None, "intent", "plain"]})
+    assert {"prompts": seen["fwd"]["prompt"], "task_out": r["task"]} == want["forward_with_tasks"]
+    r = mt.forward({"prompt": list(prompts)})
+    assert {"prompts": seen["fwd"]["prompt"], "task_out": r["task"]} == want["forward_without_tasks"]
+    r = mt.forward({"prompt": list(prompts[:2]), "task": [None, None]})
+    assert {"prompts": seen["fwd"]["prompt"], "task_out": r["task"]} == want["forward_all_none"]
+    for name, samples in (("task_sentiment", {"prompt": ["p"], "task": ["sentiment"]}),
+                          ("task_intent_overrides_batch_keys", {"prompt": ["p", "q"], "task": ["intent", "sentiment"], "max_new_tokens": 99}),
+                          ("task_plain", {"prompt": ["p"], "task": ["plain"]}),
+                          ("task_unknown", {"prompt": ["p"], "task": ["unknown"], "temperature": 0.3}),
+                          ("task_none", {"prompt": ["p"], "task": [None]}),
+                          ("no_task_key", {"prompt": ["p"]})):
+        res = mt.generate_output(samples)
+        got = {"samples_after": {k: v for k, v in seen["gen"].items() if k != "prompt"}, "current_task": mt.current_task, "n_out": len(res)}
+        assert got == want["generate_output"][name], name
