@@ -306,27 +306,35 @@ def run_inference(args) -> Dict[str, Any]:
 
 
 def save_final_results(results, args, results_dir):
-    base = f"{args.run_name}_{args.dataset_type.replace(' ', '')}_{args.input_mode}_{args.fewshot_mode}_{args.num_examples}shots"
-    if args.output_suffix:
-        base += f"_{args.output_suffix}"
-    # the reference's result records carry exactly five keys (:350-356); the first-step label logits that the data-parallel
-    # gather brings along go to a file of their own, index-aligned with the results list
-    label_logits = [r.pop("first_step_label_logits", None) for r in results]
-    with open(os.path.join(results_dir, f"{base}_results.json"), "w") as f:
-        json.dump(results, f, indent=2)
-    if any(x is not None for x in label_logits):
-        with open(os.path.join(results_dir, f"{base}_label_logits.json"), "w") as f:
-            json.dump(label_logits, f)
-    metrics = {}
-    for dt in parse_dataset_types(args.dataset_type):
-        rows = [r for r in results if r["dataset_type"] == dt.value]
-        if rows:
-            for r in rows:
-                r["predicted_label (cleaned)"] = clean_prediction(r["predicted_label"], dt)
-            metrics[dt.value] = evaluate_predictions(rows, dt)
-    with open(os.path.join(results_dir, f"{base}_metrics.json"), "w") as f:
-        json.dump(metrics, f, indent=2)
-    logger.info("Saved results and metrics under %s/%s_*.json", results_dir, base)
+    """Reference :394-456: ``{run}_{datasets}_{input_mode}_{fewshot_mode}_{k}shots[_suffix]_results.json`` (the records as
+    generated), then per dataset type the cleaned predictions + ``evaluate_predictions`` -> ``..._metrics.json``.  As in the
+    reference an error in here is logged, not raised: what was written before it stays on disk and the run still succeeds."""
+    try:
+        clean = args.dataset_type.replace(" ", "") if "-" in args.dataset_type else args.dataset_type
+        base = f"{args.run_name}_{clean}_{args.input_mode}_{args.fewshot_mode}_{args.num_examples}shots"
+        if args.output_suffix:
+            base += f"_{args.output_suffix}"
+        # the reference's result records carry exactly five keys (:350-356); the first-step label logits that the data-parallel
+        # gather brings along (SURVEY.md §8e) go to a file of their own, index-aligned with the results list
+        label_logits = [r.pop("first_step_label_logits", None) for r in results]
+        with open(os.path.join(results_dir, f"{base}_results.json"), "w") as f:
+            json.dump(results, f, indent=2)
+        if any(x is not None for x in label_logits):
+            with open(os.path.join(results_dir, f"{base}_label_logits.json"), "w") as f:
+                json.dump(label_logits, f)
+        metrics = {}
+        for dt in parse_dataset_types(args.dataset_type):
+            rows = [r for r in results if r["dataset_type"] == dt.value]
+            if rows:
+                for r in rows:
+                    r["predicted_label (cleaned)"] = clean_prediction(r["predicted_label"], dt)
+                metrics[dt.value] = evaluate_predictions(rows, dt)
+        with open(os.path.join(results_dir, f"{base}_metrics.json"), "w") as f:
+            json.dump(metrics, f, indent=2)
+        logger.info("Saved results and metrics under %s/%s_*.json", results_dir, base)
+    except Exception as e:
+        logger.error("Error saving final results: %s", e)
+        logger.debug(traceback.format_exc())
 
 
 def main(argv=None) -> int:

@@ -806,6 +806,58 @@ def g17_multi_task_wrapper():
     print("multi_task_wrapper.json written")
 
 
+def g18_results_files_and_inference_config():
+    """f1: what the reference's CLI leaves on disk — save_final_results (inference/inference.py:394-456: file names, the records as
+    dumped, the metrics file; an error inside is logged, not raised) — and config/inference_config.py's get_inference_config."""
+    import argparse
+    import tempfile
+    for name in ("SALMONN", "SALMONN.models", "SALMONN.models.salmonn_org", "peft"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["SALMONN.models.salmonn_org"].SALMONN = getattr(sys.modules["SALMONN.models.salmonn_org"], "SALMONN", object)
+    for attr in ("LoraConfig", "get_peft_model", "TaskType"):
+        setattr(sys.modules["peft"], attr, getattr(sys.modules["peft"], attr, object))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import inference.inference as ref_cli
+    from config.inference_config import get_inference_config as ref_cfg
+    from data.master_config import DatasetType as RefDT
+
+    def rec(dt, text, true, pred):
+        return {"text": text, "true_label": true, "predicted_label": pred, "dataset_type": dt}
+    results = [rec("voxceleb", "a fine day", "positive", " Positive."), rec("voxceleb", "bad", "negative", "the sentiment is neutral"),
+               rec("hvb", "thanks a lot", ["thanks", "statement_close"], "thanks, statement_close,"), rec("hvb", "is it?", ["question_check"], "none"),
+               rec("voxpopuli", "in Paris", {"place": ["Paris"]}, "place"), rec("voxpopuli", "nothing", {}, "None")]
+    out = {"save_final_results": {}}
+    for name, ns in (("multi", dict(dataset_type="voxceleb-hvb-voxpopuli", output_suffix="")),
+                     ("single_suffix", dict(dataset_type="voxceleb", output_suffix="v2")),
+                     ("bad_dataset_type", dict(dataset_type="voxceleb-notadataset", output_suffix=""))):
+        args = argparse.Namespace(run_name="run7", input_mode="speech_only", fewshot_mode="text", num_examples=5, **ns)
+        with tempfile.TemporaryDirectory() as d:
+            raised = None
+            try:
+                ref_cli.save_final_results([dict(r) for r in results], args, d)
+            except Exception as e:      # the reference logs and swallows
+                raised = f"{type(e).__name__}: {e}"
+            files = {}
+            for fn in sorted(os.listdir(d)):
+                with open(os.path.join(d, fn)) as f:
+                    files[fn] = json.load(f)
+        out["save_final_results"][name] = {"raised": raised, "files": files}
+    cfgs = {}
+    for mt in ("salmonn", "qwen2"):
+        for dt in (None,) + tuple(RefDT):
+            cfgs[f"{mt}|{dt.value if dt else None}"] = ref_cfg(mt, dt)
+    try:
+        ref_cfg("nope")
+        cfgs["nope"] = "no error"
+    except Exception as e:
+        cfgs["nope"] = f"{type(e).__name__}: {e}"
+    out["get_inference_config"] = cfgs
+    with open(os.path.join(HERE, "results_files.json"), "w") as f:
+        json.dump(out, f, indent=1, default=str)
+    print("results_files.json:", {k: list(v) for k, v in out["save_final_results"].items()})
+
+
 def g15_boundary():
     """The plugin boundary as the reference declares it: inspect.signature of BaseModel's public methods,
     ModelFactory's static methods, CustomSALMONN / CustomQwen constructors and entry points, and the action table of the
@@ -889,3 +941,4 @@ if __name__ == "__main__":
     g15_boundary()
     g16_beam_search()
     g17_multi_task_wrapper()
+    g18_results_files_and_inference_config()

@@ -691,3 +691,44 @@ def test_multi_task_wrapper_matches_the_reference():
         res = mt.generate_output(samples)
         got = {"samples_after": {k: v for k, v in seen["gen"].items() if k != "prompt"}, "current_task": mt.current_task, "n_out": len(res)}
         assert got == want["generate_output"][name], name
+
+
+def test_results_files_and_inference_config_match_the_reference(tmp_path):
+    """f1: save_final_results (inference/inference.py:394-456) leaves the same files with the same contents as the reference did on
+    the same records (tests/golden/results_files.json: multi-dataset run, single dataset with a suffix, and a bad dataset type —
+    where the reference logs the error, keeps the results file it had already written and does NOT raise), and
+    get_inference_config (config/inference_config.py) returns the same dictionaries."""
+    import argparse
+    from icl_speech_text_llm_amd.config.inference_config import get_inference_config
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType
+    from icl_speech_text_llm_amd.inference.inference import save_final_results
+    with open(os.path.join(os.path.dirname(__file__), "golden", "results_files.json")) as f:
+        want = json.load(f)
+
+    def rec(dt, text, true, pred):
+        return {"text": text, "true_label": true, "predicted_label": pred, "dataset_type": dt}
+    results = [rec("voxceleb", "a fine day", "positive", " Positive."), rec("voxceleb", "bad", "negative", "the sentiment is neutral"),
+               rec("hvb", "thanks a lot", ["thanks", "statement_close"], "thanks, statement_close,"), rec("hvb", "is it?", ["question_check"], "none"),
+               rec("voxpopuli", "in Paris", {"place": ["Paris"]}, "place"), rec("voxpopuli", "nothing", {}, "None")]
+    for name, ns in (("multi", dict(dataset_type="voxceleb-hvb-voxpopuli", output_suffix="")),
+                     ("single_suffix", dict(dataset_type="voxceleb", output_suffix="v2")),
+                     ("bad_dataset_type", dict(dataset_type="voxceleb-notadataset", output_suffix=""))):
+        args = argparse.Namespace(run_name="run7", input_mode="speech_only", fewshot_mode="text", num_examples=5, **ns)
+        d = tmp_path / name
+        d.mkdir()
+        save_final_results([dict(r) for r in results], args, str(d))          # must not raise, as the reference does not
+        files = {}
+        for fn in sorted(os.listdir(d)):
+            with open(d / fn) as f:
+                files[fn] = json.load(f)
+        assert sorted(files) == sorted(want["save_final_results"][name]["files"]), name
+        for fn, content in want["save_final_results"][name]["files"].items():
+            assert json.loads(json.dumps(files[fn], default=str)) == content, (name, fn)
+    for key, cfg in want["get_inference_config"].items():
+        if key == "nope":
+            with pytest.raises(ValueError, match=cfg.split(": ", 1)[1]):
+                get_inference_config("nope")
+            continue
+        mt, dt = key.split("|")
+        got = get_inference_config(mt, None if dt == "None" else DatasetType(dt))
+        assert json.loads(json.dumps(got, default=str)) == cfg, key
