@@ -3,8 +3,15 @@
 Mirror of the reference's inference/interactive_inference.py: same flags (:23-44), same two functions — ``setup_model(args)``
 (:46-169: ModelFactory + optional fine-tuned checkpoint + processor) and ``run_interactive_inference(model, processor, query,
 args)`` (:171-232: ``process_inputs`` of a text-only VOXCELEB-typed item with an empty completion, a one-item
-``collate_batch``, then ``generate_output`` with ``do_sample=True`` at ``--temperature`` for ``--max_new_tokens``) — and
-the same prompt loop in ``main`` (:234-281: first query from ``--query`` or stdin, then until 'exit' / 'quit' / 'q').
+``collate_batch``, then ``generate_output``) — and the same prompt loop in ``main`` (:234-281: first query from ``--query`` or
+stdin, then until 'exit' / 'quit' / 'q').
+
+The reference puts ``max_new_tokens`` / ``temperature`` / ``do_sample=True`` into the ITEM dict (:190-193); its processor's
+``collate_batch`` carries only ``prompt`` / ``completion`` / ``text`` / ``dataset_type`` next to the tensors
+(data/model_processors.py:871-874), so the knobs never reach ``generate_output`` and the reference answers every query with
+10 greedy tokens whatever the flags say (pinned by tests/golden/interactive.json, recorded from the reference's own function).
+This mirror does the same by default — same command line, same text; ``--apply_generation_flags`` (not a reference flag)
+makes ``--max_new_tokens`` / ``--temperature`` effective, i.e. sampled generation as the flag help promises.
 
 Differences, all on the host side: no CUDA_VISIBLE_DEVICES pinning and no low-memory device_map logic (one process per GPU
 owns its whole card here); ``--compile`` is accepted and ignored (there is no tracing compiler in this build); ``--seed``
@@ -40,6 +47,8 @@ def parse_args(argv=None):
     p.add_argument("--temperature", type=float, default=0.8, help="Temperature for sampling")
     p.add_argument("--arch", type=str, default=None, help="7b | 13b | tiny (default: inferred from llama_path)")
     p.add_argument("--seed", type=int, default=None, help="seed of the sampling generator (default: non-deterministic)")
+    p.add_argument("--apply_generation_flags", action="store_true",
+                   help="make --max_new_tokens / --temperature effective (the reference's collate_batch drops them: 10 greedy tokens)")
     return p.parse_args(argv)
 
 
@@ -81,11 +90,12 @@ def run_interactive_inference(model, processor, query, args):
             "max_new_tokens": args.max_new_tokens, "temperature": args.temperature, "do_sample": True, "num_examples": 0}
     batch = processor.collate_batch([item])
     batch = {k: (v.to(args.device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-    # the reference passes the generation knobs through the batch dict (generate_output reads samples.get(...))
-    batch["max_new_tokens"], batch["temperature"], batch["do_sample"] = args.max_new_tokens, args.temperature, True
-    seed = getattr(args, "seed", None)
-    if seed is not None:
-        batch["generator"] = torch.Generator().manual_seed(int(seed))
+    if getattr(args, "apply_generation_flags", False):
+        # generate_output reads the knobs from the batch dict (samples.get(...)); collate_batch has just dropped the item's copies
+        batch["max_new_tokens"], batch["temperature"], batch["do_sample"] = args.max_new_tokens, args.temperature, True
+        seed = getattr(args, "seed", None)
+        if seed is not None:
+            batch["generator"] = torch.Generator().manual_seed(int(seed))
     model.eval()
     with torch.no_grad():
         output = model.generate_output(batch)

@@ -858,6 +858,58 @@ def g18_results_files_and_inference_config():
     print("results_files.json:", {k: list(v) for k, v in out["save_final_results"].items()})
 
 
+def g19_interactive():
+    """inference/interactive_inference.py of the reference: its argparse table, and run_interactive_inference (:166-222) driven with
+    the reference's own SalmonProcessor over a byte tokenizer and a recording model — what reaches generate_output."""
+    import argparse
+    for name in ("SALMONN", "SALMONN.models", "SALMONN.models.salmonn_org", "peft"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["SALMONN.models.salmonn_org"].SALMONN = getattr(sys.modules["SALMONN.models.salmonn_org"], "SALMONN", object)
+    for attr in ("LoraConfig", "get_peft_model", "TaskType"):
+        setattr(sys.modules["peft"], attr, getattr(sys.modules["peft"], attr, object))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    captured = []
+    real_parse = argparse.ArgumentParser.parse_args
+    argparse.ArgumentParser.parse_args = lambda self, *a, **k: captured.append(self) or argparse.Namespace()
+    try:
+        sys.modules.pop("inference.interactive_inference", None)
+        import inference.interactive_inference as ref_ii
+        ref_ii.parse_args()
+    finally:
+        argparse.ArgumentParser.parse_args = real_parse
+    actions = []
+    for a in captured[0]._actions:
+        if not a.option_strings or a.dest == "help":
+            continue
+        default = "<cuda if available else cpu>" if a.dest == "device" else a.default
+        actions.append({"flags": a.option_strings, "dest": a.dest, "action": type(a).__name__,
+                        "type": getattr(a.type, "__name__", None), "default": default})
+    from data.model_processors import SalmonProcessor as RefProcessor
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    proc = RefProcessor.__new__(RefProcessor)       # its __init__ downloads the Whisper feature extractor, which text-only never calls
+    proc.tokenizer, proc.max_length, proc.batch_counter = ByteTokenizer(260), 128, 1
+    seen = {}
+
+    class Recorder:
+        def eval(self):
+            return self
+
+        def generate_output(self, batch):
+            seen["batch"] = batch
+            return ["the answer"]
+    args = argparse.Namespace(device="cpu", max_new_tokens=100, temperature=0.8)
+    text = ref_ii.run_interactive_inference(Recorder(), proc, "What is the definition of positive?", args)
+    b = seen["batch"]
+    out = {"cli": actions, "returned": text,
+           "batch_keys": sorted(b), "non_tensor": {k: (str(v) if k == "dataset_type" else v) for k, v in b.items() if not isinstance(v, torch.Tensor)},
+           "tensor_shapes": {k: list(v.shape) for k, v in b.items() if isinstance(v, torch.Tensor)},
+           "input_ids": b["input_ids"][0].tolist(), "num_examples": b["num_examples"].tolist()}
+    with open(os.path.join(HERE, "interactive.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("interactive.json: batch keys", out["batch_keys"])
+
+
 def g15_boundary():
     """The plugin boundary as the reference declares it: inspect.signature of BaseModel's public methods,
     ModelFactory's static methods, CustomSALMONN / CustomQwen constructors and entry points, and the action table of the
@@ -942,3 +994,4 @@ if __name__ == "__main__":
     g16_beam_search()
     g17_multi_task_wrapper()
     g18_results_files_and_inference_config()
+    g19_interactive()

@@ -228,11 +228,16 @@ def test_interactive_inference_text_query(monkeypatch, capsys):
     collate_batch -> generate_output with do_sample at --temperature; same seed -> same text; the prompt loop ends on 'exit'."""
     from icl_speech_text_llm_amd.inference import interactive_inference as ii
     args = ii.parse_args(["--arch", "tiny", "--device", "cuda", "--max_new_tokens", "12", "--temperature", "0.7", "--seed", "5",
-                          "--query", "What is the definition of positive?"])
+                          "--query", "What is the definition of positive?", "--apply_generation_flags"])
     model, processor = ii.setup_model(args)
     a = ii.run_interactive_inference(model, processor, args.query, args)
     b = ii.run_interactive_inference(model, processor, args.query, args)
     assert isinstance(a, str) and a == b
+    # the reference's behaviour (default): the knobs do not survive collate_batch -> the model's defaults, 10 greedy tokens
+    plain = ii.parse_args(["--arch", "tiny", "--device", "cuda", "--max_new_tokens", "12", "--temperature", "0.7", "--query", "x"])
+    g1 = ii.run_interactive_inference(model, processor, args.query, plain)
+    g2 = ii.run_interactive_inference(model, processor, args.query, plain)
+    assert g1 == g2 and len(model.llama_tokenizer(g1, add_special_tokens=False)["input_ids"]) <= 10
     args.seed = 6
     c = ii.run_interactive_inference(model, processor, "What is the definition of negative?", args)
     assert isinstance(c, str)

@@ -732,3 +732,47 @@ def test_results_files_and_inference_config_match_the_reference(tmp_path):
         mt, dt = key.split("|")
         got = get_inference_config(mt, None if dt == "None" else DatasetType(dt))
         assert json.loads(json.dumps(got, default=str)) == cfg, key
+
+
+def test_interactive_inference_matches_the_reference(monkeypatch):
+    """inference/interactive_inference.py: the reference's flags are all there with its defaults (peft_model_path aside: the authors'
+    cluster path), and run_interactive_inference hands generate_output exactly the batch the reference's own function does
+    (tests/golden/interactive.json, recorded from it): the per-item generation knobs do NOT survive collate_batch, so a query is
+    answered with the model's defaults (10 greedy tokens) unless --apply_generation_flags (ours) is given."""
+    import argparse
+    from icl_speech_text_llm_amd.data.model_processors import SalmonProcessor
+    from icl_speech_text_llm_amd.inference import interactive_inference as ii
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    with open(os.path.join(os.path.dirname(__file__), "golden", "interactive.json")) as f:
+        want = json.load(f)
+    captured = []
+    monkeypatch.setattr(argparse.ArgumentParser, "parse_args", lambda self, *a, **k: captured.append(self) or argparse.Namespace())
+    ii.parse_args([])
+    monkeypatch.undo()
+    ours = {a.dest: a for a in captured[0]._actions if a.option_strings and a.dest != "help"}
+    for ref in want["cli"]:
+        a = ours[ref["dest"]]
+        assert a.option_strings == ref["flags"] and type(a).__name__ == ref["action"] and getattr(a.type, "__name__", None) == ref["type"]
+        if ref["dest"] not in ("device", "peft_model_path"):
+            assert a.default == ref["default"], ref["dest"]
+    assert set(ours) - {r["dest"] for r in want["cli"]} == {"arch", "seed", "apply_generation_flags"}
+    seen = {}
+
+    class Recorder:
+        def eval(self):
+            return self
+
+        def generate_output(self, batch):
+            seen["batch"] = batch
+            return ["the answer"]
+    proc = SalmonProcessor(ByteTokenizer(260), max_length=128)
+    args = argparse.Namespace(device="cpu", max_new_tokens=100, temperature=0.8)
+    assert ii.run_interactive_inference(Recorder(), proc, "What is the definition of positive?", args) == want["returned"]
+    b = seen["batch"]
+    assert sorted(b) == want["batch_keys"]
+    assert {k: (str(v) if k == "dataset_type" else v) for k, v in b.items() if not isinstance(v, torch.Tensor)} == want["non_tensor"]
+    assert {k: list(v.shape) for k, v in b.items() if isinstance(v, torch.Tensor)} == want["tensor_shapes"]
+    assert b["input_ids"][0].tolist() == want["input_ids"] and b["num_examples"].tolist() == want["num_examples"]
+    args = argparse.Namespace(device="cpu", max_new_tokens=7, temperature=0.5, apply_generation_flags=True, seed=3)
+    ii.run_interactive_inference(Recorder(), proc, "q", args)
+    assert seen["batch"]["max_new_tokens"] == 7 and seen["batch"]["temperature"] == 0.5 and seen["batch"]["do_sample"] is True
