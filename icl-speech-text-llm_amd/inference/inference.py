@@ -11,9 +11,12 @@ Differences, all additive:
   * data-parallel inference: launched under ``torchrun`` (one process per GPU) the utterances are sharded
     ``i ≡ rank (mod world)`` and rank 0 gathers every rank's results before scoring (the reference's inference is
     single-process); ``--batch_size`` defaults to 64, not the reference's 1 (its collate stacks un-padded prompts, :448-450): ragged prompts
-    batch fine here and a row's results do not depend on its batch (tested bit for bit), so the default is a throughput choice
+    batch fine here and a row's speech embeddings, prefill and first-step logits do not depend on its batch (tested bit for bit;
+    later tokens within the decode kernels' tolerance), so the default is a throughput choice
     — 64 utterances keep the workspace under ~45 GiB for every supported model; ``--batch_size 256`` is the headline setting
-    (140 utterances/s on one MI355X, ~140 GiB of HBM), ``--batch_size 1`` reproduces the reference's loop shape at ~14/s.
+    (140 utterances/s on one MI355X, ~140 GiB of HBM), ``--batch_size 1`` reproduces the reference's loop shape at ~16/s.
+The host loop is pinned to the reference's own ``run_inference`` by tests/golden/cli_loop.json (records, order, failing batch,
+``--max_samples`` limiting whole batches, ``--debug_samples``, output files).
 """
 from __future__ import annotations
 
@@ -193,7 +196,11 @@ def run_inference(args) -> Dict[str, Any]:
             dataset = SyntheticICLDataset(processor, dataset_types, n_items=n_items, num_examples=args.num_examples,
                                           input_mode=args.input_mode, fewshot_mode=args.fewshot_mode, seed=1234,
                                           interleave=args.interleave)
-        total = len(dataset) if args.max_samples is None else min(len(dataset), args.max_samples)
+        # --max_samples limits WHOLE batches in the reference (`if batch_idx * batch_size >= max_samples: break`, :301-303): 3 samples
+        # at batch size 2 are 4 records (tests/golden/cli_loop.json, recorded from its run_inference)
+        total = len(dataset)
+        if args.max_samples is not None:
+            total = min(total, -(-args.max_samples // args.batch_size) * args.batch_size)
         indices = shard_indices(total, rank, world)   # i ≡ rank (mod world), no padding duplicates
         loader = DataLoader(Subset(dataset, indices), batch_size=args.batch_size, shuffle=False,
                             num_workers=args.num_workers, pin_memory=args.pin_memory and torch.cuda.is_available(),

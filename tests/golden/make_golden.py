@@ -910,6 +910,109 @@ def g19_interactive():
     print("interactive.json: batch keys", out["batch_keys"])
 
 
+CLI_LOOP_PREDICTIONS = ["positive", " Negative", "neutral.", "thanks,,", "none", "Postive", "law\n", "place, x"]     # <= 9 bytes: 10 new tokens with the EOS
+CLI_LOOP_SIZES = dict(n_items=5, n_lookup=5, n_fewshot=5, audio_seconds=(0.05, 0.15), seed=13)
+
+
+def cli_loop_prediction(prompt: str) -> str:
+    """The stand-in model of the CLI-loop golden: a fixed function of the prompt (both the reference run and ours use it)."""
+    return CLI_LOOP_PREDICTIONS[len(prompt) % len(CLI_LOOP_PREDICTIONS)]
+
+
+def g20_cli_loop():
+    """The reference's run_inference (inference/inference.py:106-392), unmodified, over seeded on-disk datasets with a stand-in model
+    (ModelFactory.create_model replaced: generate_output is `cli_loop_prediction` of each prompt, and the third batch raises): the
+    records it assembles, their order, what --max_samples really limits, what a failing batch costs, and the files it writes."""
+    import random
+    import shutil
+    import tempfile
+    from unittest import mock
+    for name in ("SALMONN", "SALMONN.models", "SALMONN.models.salmonn_org", "peft"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["SALMONN.models.salmonn_org"].SALMONN = getattr(sys.modules["SALMONN.models.salmonn_org"], "SALMONN", object)
+    for attr in ("LoraConfig", "get_peft_model", "TaskType"):
+        setattr(sys.modules["peft"], attr, getattr(sys.modules["peft"], attr, object))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from transformers import WhisperFeatureExtractor
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_synthetic_hf_datasets
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType as MyDT
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    import data.master_config as mc
+    import data.voxceleb_config as c1, data.hvb_config as c2, data.voxpopuli_config as c3, data.meld_emotion_config as c4
+    import data.model_processors as rmp
+    from utils.data_utils import clear_dataset_cache
+    import inference.inference as ref_cli
+    root = tempfile.mkdtemp(prefix="icl_golden_cli_")
+    out = {"sizes": {k: (list(v) if isinstance(v, tuple) else v) for k, v in CLI_LOOP_SIZES.items()}, "predictions": CLI_LOOP_PREDICTIONS, "runs": {}}
+    try:
+        write_synthetic_hf_datasets(root, [MyDT("voxceleb"), MyDT("hvb"), MyDT("voxpopuli")], **CLI_LOOP_SIZES)
+        seen = set()
+        for cfg in (list(mc.DATASET_CONFIGS.values()) + c1.VOXCELEB_SWAP_CONFIGS + c2.HVB_SWAP_CONFIGS + c3.VOXPOPULI_SWAP_CONFIGS
+                    + c4.MELD_EMOTION_SWAP_CONFIGS):
+            for d in (cfg.paths, cfg.audio_lookup_paths):
+                if d is not None and id(d) not in seen:
+                    seen.add(id(d))
+                    for k in list(d):
+                        d[k] = os.path.join(root, os.path.basename(d[k].rstrip("/")))
+
+        def proc_init(self, tokenizer, max_length=128):       # the reference's __init__ downloads the Whisper feature extractor
+            self.processor, self.tokenizer, self.max_length, self.batch_counter = WhisperFeatureExtractor(), tokenizer, max_length, 1
+        rmp.SalmonProcessor.__init__ = proc_init
+
+        class StandIn:
+            input_processor = None
+            llama_tokenizer = ByteTokenizer(260)
+
+            def __init__(self, fail_batch):
+                self.calls, self.fail_batch = 0, fail_batch
+
+            def to(self, *_a, **_k):
+                return self
+
+            def eval(self):
+                return self
+
+            def generate_output(self, batch):
+                self.calls += 1
+                if self.calls - 1 == self.fail_batch:
+                    raise ValueError("injected failure")
+                return [cli_loop_prediction(p) for p in batch["prompt"]]
+        real_makedirs = os.makedirs
+        for name, argv, fail in (
+                ("multi_text_only", ["--dataset_type", "voxceleb-hvb", "--input_mode", "text_only", "--num_examples", "2", "--batch_size", "2"], 2),
+                ("single_max_samples", ["--dataset_type", "voxpopuli", "--input_mode", "text_only", "--num_examples", "1", "--batch_size", "2",
+                                        "--max_samples", "3"], -1),
+                ("speech_batch1", ["--dataset_type", "voxceleb", "--input_mode", "speech_only", "--num_examples", "2", "--batch_size", "1",
+                                   "--debug_samples", "3"], -1)):
+            clear_dataset_cache()
+            random.seed(5)
+            np.random.seed(6)
+            res_dir = tempfile.mkdtemp(prefix="icl_golden_cli_res_")
+            model = StandIn(fail)
+            with mock.patch.object(sys, "argv", ["inference.py", "--peft_model_path", "", "--run_name", "g20", "--device", "cpu",
+                                                 "--num_workers", "0", "--split", "test"] + argv):
+                args = ref_cli.parse_args()
+            real_save = ref_cli.save_final_results
+            with mock.patch.object(ref_cli.ModelFactory, "create_model", staticmethod(lambda **kw: model)), \
+                    mock.patch.object(os, "makedirs", lambda p, *a, **k: real_makedirs(p, *a, **k) if not str(p).startswith("/data2") else None), \
+                    mock.patch.object(ref_cli, "save_final_results", lambda results, a, d: real_save(results, a, res_dir)):
+                ret = ref_cli.run_inference(args)
+            files = {}
+            for fn in sorted(os.listdir(res_dir)):
+                with open(os.path.join(res_dir, fn)) as f:
+                    files[fn] = json.load(f)
+            shutil.rmtree(res_dir, ignore_errors=True)
+            out["runs"][name] = {"argv": argv, "fail_batch": fail, "generate_calls": model.calls, "results": ret["results"],
+                                 "performance_keys": sorted(ret["performance"]), "total_examples": ret["performance"].get("total_examples"),
+                                 "files": files}
+        with open(os.path.join(HERE, "cli_loop.json"), "w") as f:
+            json.dump(out, f, indent=0, default=str)
+        print("cli_loop.json:", {k: (v["generate_calls"], len(v["results"])) for k, v in out["runs"].items()})
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def g15_boundary():
     """The plugin boundary as the reference declares it: inspect.signature of BaseModel's public methods,
     ModelFactory's static methods, CustomSALMONN / CustomQwen constructors and entry points, and the action table of the
@@ -995,3 +1098,4 @@ if __name__ == "__main__":
     g17_multi_task_wrapper()
     g18_results_files_and_inference_config()
     g19_interactive()
+    g20_cli_loop()

@@ -776,3 +776,55 @@ def test_interactive_inference_matches_the_reference(monkeypatch):
     args = argparse.Namespace(device="cpu", max_new_tokens=7, temperature=0.5, apply_generation_flags=True, seed=3)
     ii.run_interactive_inference(Recorder(), proc, "q", args)
     assert seen["batch"]["max_new_tokens"] == 7 and seen["batch"]["temperature"] == 0.5 and seen["batch"]["do_sample"] is True
+
+
+def test_cli_loop_matches_the_reference_run_inference(tmp_path, monkeypatch):
+    """The whole host loop of the CLI against the reference's own run_inference (inference/inference.py:106-392, run unmodified for
+    tests/golden/cli_loop.json over the same seeded on-disk datasets with the same stand-in model): record assembly and order,
+    what --max_samples really limits (whole batches: 3 -> 4 records at batch 2), a failing batch costing exactly its records,
+    --debug_samples, and the two files left on disk."""
+    import random
+    import numpy as np
+    import icl_speech_text_llm_amd.models.custom_salmon as cs
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_synthetic_hf_datasets
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType
+    from icl_speech_text_llm_amd.inference.inference import parse_args, run_inference
+    from icl_speech_text_llm_amd.runtime.salmonn import GenerateResult
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    with open(os.path.join(os.path.dirname(__file__), "golden", "cli_loop.json")) as f:
+        want = json.load(f)
+    preds = want["predictions"]
+    sizes = {k: (tuple(v) if isinstance(v, list) else v) for k, v in want["sizes"].items()}
+    root = tmp_path / "ds"
+    write_synthetic_hf_datasets(str(root), [DatasetType("voxceleb"), DatasetType("hvb"), DatasetType("voxpopuli")], **sizes)
+    monkeypatch.setattr(cs, "load_llama_tokenizer", lambda path, vocab_size=260: ByteTokenizer(260))
+    state = {}
+
+    def fake_generate_ids(self, samples, want_first_logits=False):
+        state["calls"] += 1
+        if state["calls"] - 1 == state["fail"]:
+            raise ValueError("injected failure")
+        tok = self.llama_tokenizer
+        rows = [tok(preds[len(p) % len(preds)], add_special_tokens=False, return_tensors="pt")["input_ids"].reshape(-1).tolist()
+                + [tok.eos_token_id] for p in samples["prompt"]]
+        w = max(len(r) for r in rows)
+        toks = torch.tensor([r + [tok.pad_token_id] * (w - len(r)) for r in rows], dtype=torch.int64)
+        V = max(self.cfg.llama.vocab, len(tok))
+        return GenerateResult(tokens=toks, first_logits=torch.zeros(len(rows), V) if want_first_logits else None)
+    monkeypatch.setattr(cs.CustomSALMONN, "generate_ids", fake_generate_ids)
+    for name, run in want["runs"].items():
+        state.update(calls=0, fail=run["fail_batch"])
+        random.seed(5)
+        np.random.seed(6)
+        res_dir = tmp_path / name
+        res_dir.mkdir()
+        args = parse_args(["--peft_model_path", "", "--run_name", "g20", "--device", "cpu", "--num_workers", "0", "--split", "test",
+                           "--arch", "tiny", "--dataset_root", str(root), "--results_dir", str(res_dir)] + run["argv"])
+        ret = run_inference(args)
+        assert state["calls"] == run["generate_calls"], name
+        got = [{k: v for k, v in r.items() if k != "first_step_label_logits"} for r in ret["results"]]
+        assert json.loads(json.dumps(got, default=str)) == run["results"], name
+        for fn, content in run["files"].items():
+            with open(res_dir / fn) as f:
+                assert json.load(f) == content, (name, fn)
+        assert set(run["performance_keys"]) <= set(ret["performance"]) and ret["performance"]["total_examples"] == run["total_examples"]
