@@ -166,6 +166,8 @@ def run_inference(args) -> Dict[str, Any]:
         else:
             logger.info("No checkpoint path provided, using base model without loading weights")
         model.to(args.device)
+        if isinstance(getattr(model, "generation_config", None), dict):      # Qwen2-Audio: knobs live in the model's generation config
+            model.generation_config["max_new_tokens"] = args.max_new_tokens       # (--max_new_tokens is this CLI's addition; 10 = reference)
         if args.model_type == "salmonn":
             processor = get_processor(args.model_type, model.input_processor, model.llama_tokenizer)
         else:   # the Qwen host processor computes its log-mel on the GPU: keep item processing in the main process
@@ -218,7 +220,7 @@ def run_inference(args) -> Dict[str, Any]:
                 n_b = len(batch["prompt"])
                 b_idx = indices[batch_idx * args.batch_size: batch_idx * args.batch_size + n_b]
                 try:
-                    batch["max_new_tokens"] = args.max_new_tokens
+                    batch["max_new_tokens"] = args.max_new_tokens      # SALMONN reads it from the batch dict (custom_salmon.py:708)
                     t0 = time.time()
                     res = model.generate_ids(batch, want_first_logits=True)
                     outputs = model.decode_ids(res.tokens)

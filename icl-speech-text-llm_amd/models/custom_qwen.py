@@ -6,7 +6,8 @@ input ids after it (:142-145) and returns {"loss", "logits", "labels"} (:186-197
 tokens and decodes only them with ``skip_special_tokens=True`` (:228-246); ``get_speech_embeddings`` returns four Nones
 (:117-124); ``input_processor`` exposes ``.tokenizer`` and ``.batch_decode``.  LoRA (r=8 on q_proj,k_proj, :71-80) is kept
 un-merged.  The checkpoint folder's ``generation_config.json`` is inherited as HF's ``from_pretrained`` does (sampling knobs,
-beams, the EOS id list); without one (synthetic weights) generation is greedy.  Differences: rows of different length may
+beams, the EOS id list); without one (synthetic weights) generation is greedy.  Like the reference's ``generate_output`` (:227-233)
+this one reads no generation knob from the batch dict.  Differences: rows of different length may
 share a batch (padding is stripped through ``attention_mask`` and the rows are packed); no fp16 autocast (bf16 inside).
 """
 from __future__ import annotations
@@ -276,13 +277,16 @@ class CustomQwen(BaseModel):
     def generate_ids(self, batch: Dict[str, Any], want_first_logits: bool = False):
         """Batch dict -> ``GenerateResult`` (new token ids, first-step logits on request); see CustomSALMONN.generate_ids."""
         rows, segs, speech, _, _ = self._rows_and_audio(batch)
-        # The reference calls generate(max_new_tokens=10) and inherits every other knob from the checkpoint's
-        # generation_config.json (custom_qwen.py:227-233): read at construction when ``model_path`` is a local folder, greedy
-        # otherwise; the ``generation_config`` kwarg and batch keys override it (sampled tail / beams: the SALMONN path's kernels).
-        g = {**self.generation_config, **{k: batch[k] for k in ("do_sample", "temperature", "top_p", "top_k", "repetition_penalty",
-                                                                   "generator", "num_beams", "length_penalty") if k in batch}}
+        # The reference calls generate(max_new_tokens=10) and takes EVERY other knob from the model's generation config
+        # (custom_qwen.py:227-233): keys a caller puts in the batch dict — MultiTaskModel's max_new_tokens / num_beams / do_sample /
+        # temperature among them — never reach HF there, so they are not read here either.  ``self.generation_config`` (the
+        # checkpoint folder's generation_config.json, the constructor kwarg, or assigned afterwards) is the one place to set them,
+        # ``max_new_tokens`` included; a sampling ``generator`` (not a reference key) may ride in the batch.
+        g = dict(self.generation_config)
+        if "generator" in batch:
+            g["generator"] = batch["generator"]
         eos = g.get("eos_token_id", self.cfg.llm.eos_id)          # an id or HF's list form (Qwen2-Audio: [151645, 151643])
-        res = self.runtime.generate(segs, speech, max_new_tokens=int(batch.get("max_new_tokens", 10)),
+        res = self.runtime.generate(segs, speech, max_new_tokens=int(g.get("max_new_tokens", 10)),
                                     eos_id=tuple(eos) if isinstance(eos, (list, tuple)) else int(eos),
                                     pad_id=int(g.get("pad_token_id", self.cfg.llm.pad_id)),
                                     do_sample=bool(g.get("do_sample", False)), temperature=float(g.get("temperature", 1.0)),

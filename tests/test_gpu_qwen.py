@@ -89,7 +89,17 @@ def test_forward_and_generate_match_oracle(model):
     assert e < 5e-3                      # measured 2.1e-3
     assert res.tokens.shape == (1, 5)
     # beam search through the plugin's batch keys (generation_config knobs; transformers _beam_search rules)
-    beams = model.generate_ids(dict(gen_batch, num_beams=3, length_penalty=1.0, max_new_tokens=4))
+    # the reference's generate_output reads no knob from the batch dict (max_new_tokens=10 is hard-coded, the rest is the model's
+    # generation config): keys such as MultiTaskModel's do not change the answer here either
+    plain = model.generate_ids(dict(gen_batch))
+    ignored = model.generate_ids(dict(gen_batch, num_beams=3, max_new_tokens=4, do_sample=True, temperature=0.3))
+    assert torch.equal(plain.tokens, ignored.tokens)
+    old_cfg = dict(model.generation_config)
+    try:
+        model.generation_config.update(num_beams=3, length_penalty=1.0, max_new_tokens=4)
+        beams = model.generate_ids(dict(gen_batch))
+    finally:
+        model.generation_config.clear(); model.generation_config.update(old_cfg)
     want = llm.generate_beam(emb[None, :prompt_len], 4, c.eos_id, c.pad_id, 3, 1.0)
     print(f"qwen beams: gpu {beams.tokens.tolist()} oracle {want.tolist()}")
     assert beams.tokens[0, : want.shape[1]].tolist() == want[0].tolist()
