@@ -310,6 +310,13 @@ class CustomSALMONN(BaseModel):
         object.__setattr__(self, "llama_model", self.salmonn.llama_model)
         self.llama_tokenizer = tokenizer if tokenizer is not None else load_llama_tokenizer(llama_path, cfg.llama.vocab)
         self.input_processor = HipLogMelFeatureExtractor(self)
+        # knobs the reference's generate call leaves to HF (the Llama folder's generation_config.json, else HF's defaults): top_k only
+        self.hf_generation_defaults = {"top_k": 50}
+        gc_file = os.path.join(str(llama_path), "generation_config.json") if llama_path and os.path.isdir(str(llama_path)) else None
+        if gc_file and os.path.isfile(gc_file):
+            import json
+            with open(gc_file) as fh:
+                self.hf_generation_defaults.update({k: v for k, v in json.load(fh).items() if k == "top_k" and v})
         self.batch_counter = 0
 
     # ---- nn.Module plumbing -----------------------------------------------------------------------------
@@ -545,7 +552,7 @@ class CustomSALMONN(BaseModel):
                                     eos_id=self.llama_tokenizer.eos_token_id, pad_id=self.llama_tokenizer.pad_token_id,
                                     do_sample=bool(samples.get("do_sample", False)),
                                     temperature=float(samples.get("temperature", 0.8)), top_p=float(samples.get("top_p", 0.9)),
-                                    top_k=int(samples.get("top_k", 50)),
+                                    top_k=int(self.hf_generation_defaults.get("top_k", 50)),   # not a key the reference reads (:705-715)
                                     repetition_penalty=float(samples.get("repetition_penalty", 1.0)),
                                     generator=samples.get("generator"), want_first_logits=want_first_logits,
                                     overlong="drop", num_beams=int(samples.get("num_beams", 1)),
