@@ -1013,6 +1013,40 @@ def g20_cli_loop():
         shutil.rmtree(root, ignore_errors=True)
 
 
+def g21_model_factory():
+    """models/model_factory.py of the reference: error messages of create_model / from_config, the description records, the model
+    list and clear_cache's return value (constructors are not reached by any of these calls)."""
+    for name in ("SALMONN", "SALMONN.models", "SALMONN.models.salmonn_org", "peft"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["SALMONN.models.salmonn_org"].SALMONN = getattr(sys.modules["SALMONN.models.salmonn_org"], "SALMONN", object)
+    for attr in ("LoraConfig", "get_peft_model", "TaskType"):
+        setattr(sys.modules["peft"], attr, getattr(sys.modules["peft"], attr, object))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from models.model_factory import ModelFactory as RefFactory
+
+    def err(fn):
+        try:
+            fn()
+            return None
+        except Exception as e:
+            return f"{type(e).__name__}: {e}"
+    out = {"create_model_unknown": err(lambda: RefFactory.create_model("Whisper")),
+           "create_model_multi_without_tasks": err(lambda: RefFactory.create_model("salmonn", multi_task=True)),
+           "create_model_multi_empty_tasks": err(lambda: RefFactory.create_model("QWEN2", multi_task=True, task_configs={})),
+           "from_config_no_type": err(lambda: RefFactory.from_config({})),
+           "from_config_multi_without_tasks": err(lambda: RefFactory.from_config({"model_type": "salmonn", "multi_task": True})),
+           "from_config_unknown": err(lambda: RefFactory.from_config({"model_type": "gpt"})),
+           "get_model_info": {t: RefFactory.get_model_info(t) for t in ("salmonn", "qwen2", "SALMONN")},
+           "get_model_info_unknown": err(lambda: RefFactory.get_model_info("gpt")),
+           "get_available_models": RefFactory.get_available_models(),
+           "clear_cache": RefFactory.clear_cache(),
+           "checkpoint_missing": err(lambda: RefFactory.get_model_from_checkpoint("/nonexistent/x.pt", "base", "salmonn"))}
+    with open(os.path.join(HERE, "model_factory.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("model_factory.json:", {k: (v if isinstance(v, (str, int, type(None))) else "...") for k, v in out.items()})
+
+
 def g15_boundary():
     """The plugin boundary as the reference declares it: inspect.signature of BaseModel's public methods,
     ModelFactory's static methods, CustomSALMONN / CustomQwen constructors and entry points, and the action table of the
@@ -1099,3 +1133,4 @@ if __name__ == "__main__":
     g18_results_files_and_inference_config()
     g19_interactive()
     g20_cli_loop()
+    g21_model_factory()

@@ -828,3 +828,32 @@ def test_cli_loop_matches_the_reference_run_inference(tmp_path, monkeypatch):
             with open(res_dir / fn) as f:
                 assert json.load(f) == content, (name, fn)
         assert set(run["performance_keys"]) <= set(ret["performance"]) and ret["performance"]["total_examples"] == run["total_examples"]
+
+
+def test_model_factory_messages_match_the_reference():
+    """models/model_factory.py: error messages of create_model / from_config / get_model_info / get_model_from_checkpoint, the
+    description records, the model list and clear_cache's return value, as the reference's own class produced them
+    (tests/golden/model_factory.json)."""
+    from icl_speech_text_llm_amd.models.model_factory import ModelFactory
+    with open(os.path.join(os.path.dirname(__file__), "golden", "model_factory.json")) as f:
+        want = json.load(f)
+
+    def err(fn):
+        try:
+            fn()
+            return None
+        except Exception as e:
+            return f"{type(e).__name__}: {e}"
+    got = {"create_model_unknown": err(lambda: ModelFactory.create_model("Whisper")),
+           "create_model_multi_without_tasks": err(lambda: ModelFactory.create_model("salmonn", multi_task=True)),
+           "create_model_multi_empty_tasks": err(lambda: ModelFactory.create_model("QWEN2", multi_task=True, task_configs={})),
+           "from_config_no_type": err(lambda: ModelFactory.from_config({})),
+           "from_config_multi_without_tasks": err(lambda: ModelFactory.from_config({"model_type": "salmonn", "multi_task": True})),
+           "from_config_unknown": err(lambda: ModelFactory.from_config({"model_type": "gpt"})),
+           "get_model_info": {t: ModelFactory.get_model_info(t) for t in ("salmonn", "qwen2", "SALMONN")},
+           "get_model_info_unknown": err(lambda: ModelFactory.get_model_info("gpt")),
+           "get_available_models": ModelFactory.get_available_models(),
+           "clear_cache": ModelFactory.clear_cache(),
+           "checkpoint_missing": err(lambda: ModelFactory.get_model_from_checkpoint("/nonexistent/x.pt", "base", "salmonn"))}
+    for k in want:
+        assert got[k] == want[k], (k, got[k], want[k])
