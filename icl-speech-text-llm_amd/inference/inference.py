@@ -160,6 +160,8 @@ def run_inference(args) -> Dict[str, Any]:
         model = ModelFactory.create_model(model_type=args.model_type, multi_task=False, device=args.device,
                                           low_resource=True, **model_args)
         if args.peft_model_path and args.peft_model_path.strip():
+            if not os.path.exists(args.peft_model_path):      # utils/training_utils.py:91-92 of the reference (load_checkpoint)
+                raise FileNotFoundError(f"Checkpoint file not found: {args.peft_model_path}")
             ckpt = torch.load(args.peft_model_path, map_location="cpu")
             n = load_finetuned_checkpoint(model, ckpt)
             logger.info("Updated %d parameters from %s", n, args.peft_model_path)

@@ -1006,6 +1006,46 @@ def g20_cli_loop():
             out["runs"][name] = {"argv": argv, "fail_batch": fail, "generate_calls": model.calls, "results": ret["results"],
                                  "performance_keys": sorted(ret["performance"]), "total_examples": ret["performance"].get("total_examples"),
                                  "files": files}
+        # --peft_model_path: which load_state_dict receives which keys for the four checkpoint layouts (:157-177), and a missing file
+        out["checkpoint_dispatch"] = {}
+        layouts = {"model_state_dict": lambda sd: {"model_state_dict": sd, "epoch": 3}, "state_dict": lambda sd: {"state_dict": sd},
+                   "model": lambda sd: {"model": sd}, "raw": lambda sd: sd}
+        sd = {"speech_llama_proj.weight": torch.zeros(2, 2), "llama_model.base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight": torch.ones(1, 2)}
+        for lname, wrap in list(layouts.items()) + [("missing_file", None)]:
+            clear_dataset_cache()
+            random.seed(5)
+            np.random.seed(6)
+            res_dir = tempfile.mkdtemp(prefix="icl_golden_cli_res_")
+            ck = os.path.join(res_dir, "ck.pt")
+            if wrap is not None:
+                torch.save(wrap(sd), ck)
+            calls = []
+
+            class Inner:
+                def load_state_dict(self, state, strict=True):
+                    calls.append(["model.salmonn.load_state_dict", sorted(state), strict])
+
+            class Recording(StandIn):
+                salmonn = Inner()
+
+                def load_state_dict(self, state, strict=True):
+                    calls.append(["model.load_state_dict", sorted(state), strict])
+            model = Recording(-1)
+            with mock.patch.object(sys, "argv", ["inference.py", "--peft_model_path", ck, "--run_name", "g20", "--device", "cpu",
+                                                 "--num_workers", "0", "--split", "test", "--dataset_type", "voxceleb", "--input_mode",
+                                                 "text_only", "--num_examples", "1", "--batch_size", "1", "--debug_samples", "1"]):
+                args = ref_cli.parse_args()
+            real_save = ref_cli.save_final_results
+            error = None
+            with mock.patch.object(ref_cli.ModelFactory, "create_model", staticmethod(lambda **kw: model)), \
+                    mock.patch.object(os, "makedirs", lambda p, *a, **k: real_makedirs(p, *a, **k) if not str(p).startswith("/data2") else None), \
+                    mock.patch.object(ref_cli, "save_final_results", lambda results, a, d: real_save(results, a, res_dir)):
+                try:
+                    ret = ref_cli.run_inference(args)
+                except Exception as e:
+                    error = f"{type(e).__name__}: {e}".replace(ck, "<ckpt>")
+            shutil.rmtree(res_dir, ignore_errors=True)
+            out["checkpoint_dispatch"][lname] = {"calls": calls, "error": error, "n_results": None if error else len(ret["results"])}
         with open(os.path.join(HERE, "cli_loop.json"), "w") as f:
             json.dump(out, f, indent=0, default=str)
         print("cli_loop.json:", {k: (v["generate_calls"], len(v["results"])) for k, v in out["runs"].items()})

@@ -857,3 +857,36 @@ def test_model_factory_messages_match_the_reference():
            "checkpoint_missing": err(lambda: ModelFactory.get_model_from_checkpoint("/nonexistent/x.pt", "base", "salmonn"))}
     for k in want:
         assert got[k] == want[k], (k, got[k], want[k])
+
+
+def test_checkpoint_dispatch_matches_the_reference(tmp_path):
+    """--peft_model_path (inference/inference.py:157-177): which load_state_dict receives the keys for the four checkpoint layouts,
+    always strict=False, as recorded from the reference's run_inference (tests/golden/cli_loop.json, `checkpoint_dispatch`); a
+    missing file fails the run with the reference's message."""
+    from icl_speech_text_llm_amd.inference import inference as cli
+    from icl_speech_text_llm_amd.models.model_factory import load_finetuned_checkpoint
+    with open(os.path.join(os.path.dirname(__file__), "golden", "cli_loop.json")) as f:
+        want = json.load(f)["checkpoint_dispatch"]
+    sd = {"speech_llama_proj.weight": torch.zeros(2, 2),
+          "llama_model.base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight": torch.ones(1, 2)}
+    layouts = {"model_state_dict": {"model_state_dict": sd, "epoch": 3}, "state_dict": {"state_dict": sd}, "model": {"model": sd}, "raw": sd}
+    for name, ckpt in layouts.items():
+        calls = []
+
+        class Inner:
+            def load_state_dict(self, state, strict=True):
+                calls.append(["model.salmonn.load_state_dict", sorted(state), strict])
+
+        class Recording:
+            salmonn = Inner()
+
+            def load_state_dict(self, state, strict=True):
+                calls.append(["model.load_state_dict", sorted(state), strict])
+        assert load_finetuned_checkpoint(Recording(), ckpt) == len(sd)
+        assert calls == want[name]["calls"], name
+    args = cli.parse_args(["--peft_model_path", str(tmp_path / "nope.pt"), "--run_name", "x", "--dataset_type", "voxceleb", "--device", "cpu",
+                           "--arch", "tiny", "--synthetic_items", "1", "--num_workers", "0", "--input_mode", "text_only",
+                           "--results_dir", str(tmp_path)])
+    with pytest.raises(RuntimeError) as e:
+        cli.run_inference(args)
+    assert f"{type(e.value).__name__}: {e.value}".replace(str(tmp_path / "nope.pt"), "<ckpt>") == want["missing_file"]["error"]
