@@ -402,3 +402,42 @@ def test_pretrained_hf_folders_are_ingested(tmp_path):
     enc = rt.whisper.forward(rt.ws, rt.logmel.from_spectrogram(rt.ws, spec.to("cuda")))
     relw = float((enc.float().cpu().reshape(want.shape) - want).norm() / want.norm())
     assert relw < 2e-2, relw
+
+
+def test_cli_end_to_end_matches_the_reference_cli(tmp_path, monkeypatch):
+    """The reference's CLI against this build's CLI, end to end, on the GPU.  tests/golden/cli_e2e.json holds what the reference's
+    run_inference — over its own CustomSALMONN (unmodified; the absent SALMONN package stubbed by a two-layer HF Llama of this
+    build's `tiny` width + the byte tokenizer), text_only mode, seeded on-disk datasets — wrote: six records and two files.  The
+    same datasets, the same Llama weights (loaded through --peft_model_path, the reference's {"model": ...} checkpoint layout)
+    and the same command line must give the same records here: prompt assembly, tokenisation, embedding, prefill + 10 greedy
+    decode steps on the HIP kernels, decoding, cleaning, scoring.  The Llama's seed was picked so that every one of the 60 greedy
+    decisions has a margin of more than 8x the fp32-vs-bf16 oracle distance at that step (10.2x at the tightest)."""
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_synthetic_hf_datasets
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType
+    from icl_speech_text_llm_amd.inference import inference as cli
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    with open(os.path.join(gold, "cli_e2e.json")) as f:
+        want = json.load(f)
+    z = np.load(os.path.join(gold, "cli_e2e_llama.npz"))
+    sd = {"llama_model." + k[len("w16:"):]: torch.from_numpy(z[k].astype(np.int32) << 16).view(torch.float32) for k in z.files}
+    ckpt = tmp_path / "llama.pt"
+    torch.save({"model": sd}, ckpt)
+    root = tmp_path / "ds"
+    sizes = {k: (tuple(v) if isinstance(v, list) else v) for k, v in want["sizes"].items()}
+    write_synthetic_hf_datasets(str(root), [DatasetType("voxceleb"), DatasetType("hvb")], **sizes)
+    monkeypatch.setattr(cli, "get_inference_config", lambda model_type: {"model_args": {"lora": False, "llama_path": "none"}})
+    res = tmp_path / "res"
+    res.mkdir()
+    import random
+    random.seed(5)
+    np.random.seed(6)
+    args = cli.parse_args(["--peft_model_path", str(ckpt), "--run_name", "e2e", "--device", "cuda", "--num_workers", "0", "--split", "test",
+                           "--arch", "tiny", "--dataset_root", str(root), "--results_dir", str(res)] + want["argv"])
+    ret = cli.run_inference(args)
+    got = [{k: v for k, v in r.items() if k != "first_step_label_logits"} for r in ret["results"]]
+    for g, w in zip(got, want["results"]):
+        print("e2e:", repr(g["predicted_label"]), "| reference:", repr(w["predicted_label"]))
+    assert json.loads(json.dumps(got, default=str)) == want["results"]
+    for fn, content in want["files"].items():
+        with open(res / fn) as f:
+            assert json.load(f) == content, fn
