@@ -19,10 +19,10 @@ def load_dataset(dataset_type: DatasetType, split="train", use_cache: bool = Tru
     if isinstance(split, str):
         split = DatasetSplit({"val": "validation"}.get(split, split))     # the CLI says "val", the enum "validation"
     dataset_type = DatasetType(dataset_type)
-    key = f"{dataset_type.value}_{split.value}"
+    path = get_dataset_config(base_type_for_loading(dataset_type)).get_path(split)
+    key = f"{dataset_type.value}_{split.value}|{path}"      # the folder is part of the key: --dataset_root may re-root a task between runs
     if use_cache and key in _DATASET_CACHE:
         return _DATASET_CACHE[key]
-    path = get_dataset_config(base_type_for_loading(dataset_type)).get_path(split)
     if not os.path.exists(path):
         raise FileNotFoundError(f"Dataset file not found: {path}")
     from datasets import load_from_disk

@@ -1230,6 +1230,162 @@ def g22_cli_end_to_end():
         shutil.rmtree(root, ignore_errors=True)
 
 
+E2E_SPEECH_SIZES = dict(n_items=2, n_lookup=4, n_fewshot=4, audio_seconds=(0.4, 0.9), seed=19)
+E2E_SPEECH_RUNS = {"speech_query_text_exemplars": ["--dataset_type", "voxceleb-hvb", "--input_mode", "speech_only", "--fewshot_mode", "text",
+                                                   "--num_examples", "2", "--batch_size", "1"],
+                   "speech_query_speech_exemplars": ["--dataset_type", "voxceleb", "--input_mode", "speech_only", "--fewshot_mode", "speech",
+                                                     "--num_examples", "2", "--batch_size", "1"]}
+
+
+def g23_cli_end_to_end_speech():
+    """g22 with audio: the reference's CLI over its own CustomSALMONN in speech_only mode (a speech query after two text exemplars;
+    a speech query after two SPEECH exemplars).  Everything in the reference's repository runs unmodified — dataset items, the
+    Whisper feature extractor, prompt split, `<Speech>` interleave of query and exemplar embeddings, HF generate, decoding, scoring —
+    and the one thing it imports from the absent SALMONN package, `encode_speech`, is this repo's fp32 oracle of it (Whisper + BEATs
+    + window-level Q-Former over `tests/golden/e2e_weights.py`'s miniature weights).  What the golden pins beyond the oracle is
+    the integration: which audio goes where in which prompt, and that the whole chain yields these tokens."""
+    import random
+    import shutil
+    import tempfile
+    from unittest import mock
+    from transformers import LlamaConfig, LlamaForCausalLM, WhisperFeatureExtractor
+    for name in ("SALMONN", "SALMONN.models", "SALMONN.models.salmonn_org", "peft"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for attr in ("LoraConfig", "get_peft_model", "TaskType"):
+        setattr(sys.modules["peft"], attr, getattr(sys.modules["peft"], attr, object))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sys.path.insert(0, HERE)
+    from e2e_weights import tiny_salmonn_weights
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_synthetic_hf_datasets
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType as MyDT
+    from icl_speech_text_llm_amd.utils.tokenization import ByteTokenizer
+    from oracle import models as om
+    import data.master_config as mc
+    import data.voxceleb_config as c1, data.hvb_config as c2, data.voxpopuli_config as c3, data.meld_emotion_config as c4
+    import data.model_processors as rmp
+    from utils.data_utils import clear_dataset_cache
+    tok = ByteTokenizer(260)
+    holder = {}
+
+    class StubSALMONN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.llama_model, self.llama_tokenizer = holder["llama"], tok
+
+        @classmethod
+        def from_config(cls, cfg):
+            return cls()
+
+        def encode_speech(self, spectrogram=None, raw_wav=None, audio_padding_mask=None):
+            cfg, sd = holder["cfg"], holder["sd"]
+            lens = ((~audio_padding_mask.bool()).sum(1).tolist() if audio_padding_mask is not None else [raw_wav.shape[1]] * raw_wav.shape[0])
+            emb = om.salmonn_encode_speech(sd, spectrogram.float(), raw_wav.float(), lens, cfg.whisper.n_heads,
+                                           beats_cfg=dict(n_heads=cfg.beats.n_heads), qformer_heads=cfg.qformer.n_heads)
+            if holder.get("mute"):          # control run: does the answer depend on the audio at all?
+                emb = torch.zeros_like(emb)
+            return emb, torch.ones(emb.shape[:2], dtype=torch.long)
+    sys.modules["SALMONN.models.salmonn_org"].SALMONN = StubSALMONN
+    for m in ("models.custom_salmon", "models.model_factory", "models.multi_task_model", "inference.inference"):
+        sys.modules.pop(m, None)
+    import inference.inference as ref_cli
+
+    def proc_init(self, tokenizer, max_length=128):
+        self.processor, self.tokenizer, self.max_length, self.batch_counter = WhisperFeatureExtractor(), tokenizer, max_length, 1
+    rmp.SalmonProcessor.__init__ = proc_init
+    root = tempfile.mkdtemp(prefix="icl_golden_e2es_")
+    real_makedirs = os.makedirs
+    try:
+        write_synthetic_hf_datasets(root, [MyDT("voxceleb"), MyDT("hvb")], **E2E_SPEECH_SIZES)
+        seen = set()
+        for cfg_ in (list(mc.DATASET_CONFIGS.values()) + c1.VOXCELEB_SWAP_CONFIGS + c2.HVB_SWAP_CONFIGS + c3.VOXPOPULI_SWAP_CONFIGS
+                     + c4.MELD_EMOTION_SWAP_CONFIGS):
+            for d in (cfg_.paths, cfg_.audio_lookup_paths):
+                if d is not None and id(d) not in seen:
+                    seen.add(id(d))
+                    for k in list(d):
+                        d[k] = os.path.join(root, os.path.basename(d[k].rstrip("/")))
+        chosen = None
+        # seeds 0..119 were searched once (9 minutes); 115 is the first above 12x (15.2x), so the search starts there
+        for seed in range(int(os.environ.get("G23_FIRST_SEED", "115")), 400):
+            cfg, sd = tiny_salmonn_weights(seed)
+            lc = cfg.llama
+            llama = LlamaForCausalLM(LlamaConfig(hidden_size=lc.hidden, intermediate_size=lc.ffn, num_hidden_layers=lc.n_layers,
+                                                 num_attention_heads=lc.n_heads, num_key_value_heads=lc.n_heads, vocab_size=lc.vocab,
+                                                 rms_norm_eps=lc.rms_eps, max_position_embeddings=lc.max_pos, pad_token_id=lc.pad_id,
+                                                 bos_token_id=lc.bos_id, eos_token_id=lc.eos_id, tie_word_embeddings=False)).eval()
+            lsd = {k[len("llama_model."):]: v for k, v in sd.items() if k.startswith("llama_model.")}
+            missing, unexpected = llama.load_state_dict(lsd, strict=False)
+            assert not unexpected and all("rotary" in m for m in missing), (missing, unexpected)
+            holder.update(llama=llama, cfg=cfg, sd=sd)
+            captured = []
+            real_generate = llama.generate
+
+            def spy(*a, **k):
+                out_ids = real_generate(*a, **k)
+                captured.append((k["inputs_embeds"].detach().clone(), out_ids.detach().clone()))
+                return out_ids
+            llama.generate = spy
+            runs = {}
+            for name, argv in list(E2E_SPEECH_RUNS.items()) + [("muted_control", E2E_SPEECH_RUNS["speech_query_text_exemplars"])]:
+                holder["mute"] = name == "muted_control"
+                if holder["mute"]:
+                    n_real = len(captured)          # the control's decisions are not part of the golden: no margin asked of them
+                clear_dataset_cache()
+                random.seed(5)
+                np.random.seed(6)
+                res_dir = tempfile.mkdtemp(prefix="icl_golden_e2es_res_")
+                with mock.patch.object(sys, "argv", ["inference.py", "--peft_model_path", "", "--run_name", "e2e", "--device", "cpu",
+                                                     "--num_workers", "0", "--split", "test"] + argv):
+                    args = ref_cli.parse_args()
+                real_save = ref_cli.save_final_results
+                real_create = ref_cli.ModelFactory.create_model
+
+                def create(**kw):
+                    model = real_create(**{**kw, "lora": False, "low_resource": False})
+                    model.input_processor = None      # see g22
+                    return model
+                with mock.patch.object(ref_cli.ModelFactory, "create_model", staticmethod(create)), \
+                        mock.patch.object(os, "makedirs", lambda p, *a, **k: real_makedirs(p, *a, **k) if not str(p).startswith("/data2") else None), \
+                        mock.patch.object(ref_cli, "save_final_results", lambda results, a, d: real_save(results, a, res_dir)):
+                    ret = ref_cli.run_inference(args)
+                files = {}
+                for fn in sorted(os.listdir(res_dir)):
+                    with open(os.path.join(res_dir, fn)) as f:
+                        files[fn] = json.load(f)
+                shutil.rmtree(res_dir, ignore_errors=True)
+                runs[name] = {"argv": argv, "results": ret["results"], "files": files}
+            of, ob = om.LlamaOracle(lsd, lc.n_heads, lc.rms_eps), om.LlamaOracle(lsd, lc.n_heads, lc.rms_eps, rnd=om.bf16_round)
+            worst = float("inf")
+            for emb, ids in captured[:n_real]:
+                ids = ids[:, : max(1, int((ids[0] != lc.pad_id).sum()))]
+                lf, lb = of.teacher_forced_logits(emb, ids)[0], ob.teacher_forced_logits(emb, ids)[0]
+                for t in range(ids.shape[1]):
+                    top2 = lf[t].topk(2)
+                    if int(top2.indices[0]) != int(ids[0, t]) or int(lb[t].argmax()) != int(ids[0, t]):
+                        worst = -1.0
+                        break
+                    worst = min(worst, float(top2.values[0] - top2.values[1]) / max(float((lf[t] - lb[t]).abs().max()), 1e-6))
+                if worst < 0:
+                    break
+            muted = runs.pop("muted_control")
+            hears = [a["predicted_label"] != b["predicted_label"] for a, b in zip(runs["speech_query_text_exemplars"]["results"], muted["results"])]
+            print(f"seed {seed}: {sum(len(r['results']) for r in runs.values())} records, smallest margin / bf16 distance = {worst:.1f}, "
+                  f"answers that change when the audio is muted: {sum(hears)}/{len(hears)}")
+            if worst > 12.0 and all(hears):
+                chosen = (seed, runs, worst)
+                break
+        assert chosen is not None, "no seed with decisive margins"
+        seed, runs, worst = chosen
+        with open(os.path.join(HERE, "cli_e2e_speech.json"), "w") as f:
+            json.dump({"sizes": {k: (list(v) if isinstance(v, tuple) else v) for k, v in E2E_SPEECH_SIZES.items()}, "weights_seed": seed,
+                       "smallest_margin_over_bf16_distance": worst, "answers_change_when_audio_is_muted": True,
+                       "runs": runs}, f, indent=0, default=str)
+        print("cli_e2e_speech.json:", {k: [r["predicted_label"] for r in v["results"]] for k, v in runs.items()})
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def g15_boundary():
     """The plugin boundary as the reference declares it: inspect.signature of BaseModel's public methods,
     ModelFactory's static methods, CustomSALMONN / CustomQwen constructors and entry points, and the action table of the
@@ -1318,3 +1474,4 @@ if __name__ == "__main__":
     g20_cli_loop()
     g21_model_factory()
     g22_cli_end_to_end()
+    g23_cli_end_to_end_speech()

@@ -441,3 +441,60 @@ def test_cli_end_to_end_matches_the_reference_cli(tmp_path, monkeypatch):
     for fn, content in want["files"].items():
         with open(res / fn) as f:
             assert json.load(f) == content, fn
+
+
+def test_cli_end_to_end_speech_matches_the_reference_cli(tmp_path, monkeypatch):
+    """The speech modes end to end against the reference's CLI (tests/golden/cli_e2e_speech.json: its run_inference + CustomSALMONN,
+    unmodified, with `encode_speech` of the absent SALMONN package supplied by this repo's fp32 oracle over the miniature weights of
+    tests/golden/e2e_weights.py): a speech query after two text exemplars (two tasks) and after two SPEECH exemplars.  This build's
+    CLI on the GPU — raw audio -> log-mel -> Whisper + BEATs -> Q-Former -> interleave -> prefill -> 10 greedy tokens — must write the
+    same records and files; the golden's answers change when its audio is muted, and its tightest greedy margin is 15x the
+    fp32-vs-bf16 oracle distance."""
+    import random
+    import sys
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_synthetic_hf_datasets
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType
+    from icl_speech_text_llm_amd.inference import inference as cli
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, gold)
+    from e2e_weights import tiny_salmonn_weights
+    with open(os.path.join(gold, "cli_e2e_speech.json")) as f:
+        want = json.load(f)
+    _, sd = tiny_salmonn_weights(int(want["weights_seed"]))
+    ckpt = tmp_path / "salmonn.pt"
+    torch.save({"model": sd}, ckpt)
+    root = tmp_path / "ds"
+    sizes = {k: (tuple(v) if isinstance(v, list) else v) for k, v in want["sizes"].items()}
+    write_synthetic_hf_datasets(str(root), [DatasetType("voxceleb"), DatasetType("hvb")], **sizes)
+    monkeypatch.setattr(cli, "get_inference_config",
+                        lambda model_type: {"model_args": {"lora": False, "llama_path": "none", "beats_path": "synthetic"}})
+    for name, run in want["runs"].items():
+        res = tmp_path / name
+        res.mkdir()
+        random.seed(5)
+        np.random.seed(6)
+        args = cli.parse_args(["--peft_model_path", str(ckpt), "--run_name", "e2e", "--device", "cuda", "--num_workers", "0", "--split", "test",
+                               "--arch", "tiny", "--dataset_root", str(root), "--results_dir", str(res)] + run["argv"])
+        ret = cli.run_inference(args)
+        got = [{k: v for k, v in r.items() if k != "first_step_label_logits"} for r in ret["results"]]
+        for g, w in zip(got, run["results"]):
+            print(f"e2e {name}:", repr(g["predicted_label"]), "| reference:", repr(w["predicted_label"]))
+        assert json.loads(json.dumps(got, default=str)) == run["results"], name
+        for fn, content in run["files"].items():
+            with open(res / fn) as f:
+                assert json.load(f) == content, (name, fn)
+    # control: with the speech embeddings zeroed the answers change, as the golden's did when ITS audio was muted — the match above
+    # is not indifferent to the audio path
+    from icl_speech_text_llm_amd.runtime.salmonn import SalmonnRuntime
+    real = SalmonnRuntime.encode_speech
+    monkeypatch.setattr(SalmonnRuntime, "encode_speech", lambda self, *a, **k: torch.zeros_like(real(self, *a, **k)))
+    run = want["runs"]["speech_query_text_exemplars"]
+    res = tmp_path / "muted"
+    res.mkdir()
+    random.seed(5)
+    np.random.seed(6)
+    args = cli.parse_args(["--peft_model_path", str(ckpt), "--run_name", "e2e", "--device", "cuda", "--num_workers", "0", "--split", "test",
+                           "--arch", "tiny", "--dataset_root", str(root), "--results_dir", str(res)] + run["argv"])
+    muted = cli.run_inference(args)["results"]
+    assert want["answers_change_when_audio_is_muted"] and len(muted) == len(run["results"])
+    assert all(m["predicted_label"] != w["predicted_label"] for m, w in zip(muted, run["results"]))
