@@ -246,6 +246,9 @@ def run_inference(args) -> Dict[str, Any]:
                         rows[b_idx[i]] = {"text": batch["text"][i], "true_label": true_label,
                                           "predicted_label (cleaned)": clean_prediction(out, dt_i),
                                           "predicted_label": out.strip(), "dataset_type": DatasetType(dt_i).value}
+                        if DatasetType(dt_i).value == "sqa":      # reference :358-361: SQA records carry the question text too
+                            q = batch["question"]
+                            rows[b_idx[i]]["question"] = q[i] if isinstance(q, list) else q
                     tracker.update(dt, len(keep))
                 except (torch.cuda.OutOfMemoryError, IclError) as e:
                     # device-side failures are not "a bad sample": stop with a non-zero exit code — on EVERY rank (the others
@@ -276,8 +279,8 @@ def run_inference(args) -> Dict[str, Any]:
             got = gather_results(dist, args.device, torch.tensor(idx_l, dtype=torch.int64),
                                  cat(ids_l, (0, args.max_new_tokens), torch.int32), cat(len_l, (0,), torch.int32),
                                  cat(logit_l, (0, len(label_ids)), torch.bfloat16), per_rank)
-            meta = gather_json_records(dist, args.device, [{k: rows[i][k] for k in ("text", "true_label", "dataset_type")}
-                                                           for i in idx_l], idx_l, per_rank)
+            meta = gather_json_records(dist, args.device, [{k: rows[i][k] for k in ("text", "true_label", "dataset_type", "question")
+                                                            if k in rows[i]} for i in idx_l], idx_l, per_rank)
             if rank == 0:
                 texts = model.decode_ids(got["gen_ids"].cpu().to(torch.int64))
                 rows = {}
@@ -286,6 +289,8 @@ def run_inference(args) -> Dict[str, Any]:
                     rows[i] = {"text": m["text"], "true_label": m["true_label"],
                                "predicted_label (cleaned)": clean_prediction(texts[r], DatasetType(m["dataset_type"])),
                                "predicted_label": texts[r].strip(), "dataset_type": m["dataset_type"]}
+                    if "question" in m:
+                        rows[i]["question"] = m["question"]
                     if label_names:
                         rows[i]["first_step_label_logits"] = dict(zip(label_names, got["first_logits"][r].float().tolist()))
             counts = torch.tensor([perf["total_examples"], failed_batches], dtype=torch.float64,

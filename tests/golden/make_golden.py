@@ -1234,7 +1234,9 @@ E2E_SPEECH_SIZES = dict(n_items=2, n_lookup=4, n_fewshot=4, audio_seconds=(0.4, 
 E2E_SPEECH_RUNS = {"speech_query_text_exemplars": ["--dataset_type", "voxceleb-hvb", "--input_mode", "speech_only", "--fewshot_mode", "text",
                                                    "--num_examples", "2", "--batch_size", "1"],
                    "speech_query_speech_exemplars": ["--dataset_type", "voxceleb", "--input_mode", "speech_only", "--fewshot_mode", "speech",
-                                                     "--num_examples", "2", "--batch_size", "1"]}
+                                                     "--num_examples", "2", "--batch_size", "1"],
+                   "sqa_two_audios_speech_exemplar": ["--dataset_type", "sqa", "--input_mode", "speech_only", "--fewshot_mode", "speech",
+                                                      "--num_examples", "1", "--batch_size", "1"]}
 
 
 def g23_cli_end_to_end_speech():
@@ -1296,7 +1298,7 @@ def g23_cli_end_to_end_speech():
     root = tempfile.mkdtemp(prefix="icl_golden_e2es_")
     real_makedirs = os.makedirs
     try:
-        write_synthetic_hf_datasets(root, [MyDT("voxceleb"), MyDT("hvb")], **E2E_SPEECH_SIZES)
+        write_synthetic_hf_datasets(root, [MyDT("voxceleb"), MyDT("hvb"), MyDT("sqa")], **E2E_SPEECH_SIZES)
         seen = set()
         for cfg_ in (list(mc.DATASET_CONFIGS.values()) + c1.VOXCELEB_SWAP_CONFIGS + c2.HVB_SWAP_CONFIGS + c3.VOXPOPULI_SWAP_CONFIGS
                      + c4.MELD_EMOTION_SWAP_CONFIGS):
