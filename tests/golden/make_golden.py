@@ -1236,7 +1236,9 @@ E2E_SPEECH_RUNS = {"speech_query_text_exemplars": ["--dataset_type", "voxceleb-h
                    "speech_query_speech_exemplars": ["--dataset_type", "voxceleb", "--input_mode", "speech_only", "--fewshot_mode", "speech",
                                                      "--num_examples", "2", "--batch_size", "1"],
                    "sqa_two_audios_speech_exemplar": ["--dataset_type", "sqa", "--input_mode", "speech_only", "--fewshot_mode", "speech",
-                                                      "--num_examples", "1", "--batch_size", "1"]}
+                                                      "--num_examples", "1", "--batch_size", "1"],
+                   "speech_and_text_zero_shot": ["--dataset_type", "hvb", "--input_mode", "speech_and_text", "--fewshot_mode", "text",
+                                                 "--num_examples", "0", "--batch_size", "1"]}
 
 
 def g23_cli_end_to_end_speech():

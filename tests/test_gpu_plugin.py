@@ -446,8 +446,8 @@ def test_cli_end_to_end_matches_the_reference_cli(tmp_path, monkeypatch):
 def test_cli_end_to_end_speech_matches_the_reference_cli(tmp_path, monkeypatch):
     """The speech modes end to end against the reference's CLI (tests/golden/cli_e2e_speech.json: its run_inference + CustomSALMONN,
     unmodified, with `encode_speech` of the absent SALMONN package supplied by this repo's fp32 oracle over the miniature weights of
-    tests/golden/e2e_weights.py): a speech query after two text exemplars (two tasks), after two SPEECH exemplars, and an SQA item (question + document audio, one
-    two-audio speech exemplar).  This build's
+    tests/golden/e2e_weights.py): a speech query after two text exemplars (two tasks), after two SPEECH exemplars, an SQA item (question + document audio, one
+    two-audio speech exemplar) and a zero-shot speech_and_text prompt.  This build's
     CLI on the GPU — raw audio -> log-mel -> Whisper + BEATs -> Q-Former -> interleave -> prefill -> 10 greedy tokens — must write the
     same records and files; the golden's answers change when its audio is muted, and its tightest greedy margin is 15x the
     fp32-vs-bf16 oracle distance."""
