@@ -441,6 +441,19 @@ def test_cli_end_to_end_matches_the_reference_cli(tmp_path, monkeypatch):
     for fn, content in want["files"].items():
         with open(res / fn) as f:
             assert json.load(f) == content, fn
+    # the reference can only run batch 1 (its collate stacks un-padded prompts); this CLI batches ragged prompts and must still write
+    # the reference's records: the six utterances in one batch of 4 and one of 2
+    res4 = tmp_path / "res4"
+    res4.mkdir()
+    random.seed(5)
+    np.random.seed(6)
+    argv4 = [a if a != "1" or want["argv"][i - 1] != "--batch_size" else "4" for i, a in enumerate(want["argv"])]
+    assert "4" in argv4
+    args = cli.parse_args(["--peft_model_path", str(ckpt), "--run_name", "e2e", "--device", "cuda", "--num_workers", "0", "--split", "test",
+                           "--arch", "tiny", "--dataset_root", str(root), "--results_dir", str(res4)] + argv4)
+    ret4 = cli.run_inference(args)
+    got4 = [{k: v for k, v in r.items() if k != "first_step_label_logits"} for r in ret4["results"]]
+    assert json.loads(json.dumps(got4, default=str)) == want["results"]
 
 
 def test_cli_end_to_end_speech_matches_the_reference_cli(tmp_path, monkeypatch):
