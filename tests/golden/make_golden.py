@@ -1390,6 +1390,79 @@ def g23_cli_end_to_end_speech():
         shutil.rmtree(root, ignore_errors=True)
 
 
+def g24_qwen_glue_end_to_end():
+    """The reference's CustomQwen (models/custom_qwen.py, unmodified: `forward` with its prompt_length label mask, `generate_output`
+    with generate(max_new_tokens=10) + slice + decode) over HF Qwen2AudioForConditionalGeneration at this build's `tiny` dims
+    (`from_pretrained` / `AutoProcessor.from_pretrained` replaced: no checkpoint is reachable; `peft` is an empty module, lora=False).
+    Golden: labels, loss, logits at the last positions, and the ten generated ids — with a weights seed whose greedy margins are
+    more than 12x the fp32-vs-bf16 oracle distance (audio tower + decoder), for the GPU test of this build's CustomQwen."""
+    for name in ("peft",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for attr in ("LoraConfig", "get_peft_model", "TaskType"):
+        setattr(sys.modules["peft"], attr, getattr(sys.modules["peft"], attr, object))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sys.path.insert(0, HERE)
+    from e2e_weights import qwen_batch, tiny_qwen_hf_model
+    from icl_speech_text_llm_amd.runtime.qwen import normalize_qwen_keys
+    from oracle import models as om
+    sys.modules.pop("models.custom_qwen", None)
+    import models.custom_qwen as rq
+    holder = {}
+
+    class Decoder:
+        class tokenizer:
+            @staticmethod
+            def decode(ids, **k):
+                return " ".join(str(int(i)) for i in ids)
+
+        @staticmethod
+        def batch_decode(ids, skip_special_tokens=True, clean_up_tokenization_spaces=False):
+            return [" ".join(str(int(i)) for i in row) for row in ids]
+    rq.Qwen2AudioForConditionalGeneration.from_pretrained = classmethod(lambda cls, *a, **k: holder["hf"])
+    rq.AutoProcessor.from_pretrained = staticmethod(lambda *a, **k: Decoder())
+    chosen = None
+    for seed in range(int(os.environ.get("G24_FIRST_SEED", "0")), 300):
+        cfg, hf = tiny_qwen_hf_model(seed)
+        holder["hf"] = hf
+        ref = rq.CustomQwen(model_path="none", lora=False, device=torch.device("cpu"), use_fp16=False)
+        ref.batch_counter = 1
+        batch, prompt_len = qwen_batch(cfg)
+        with torch.no_grad():
+            fwd = ref.forward(dict(batch))
+            gen_batch = {k: (v[:, :prompt_len] if k in ("input_ids", "attention_mask") else v) for k, v in batch.items()}
+            text = ref.generate_output(dict(gen_batch))
+        gen_ids = [int(t) for t in text[0].split()]
+        # margins against the fp32 / bf16-rounding oracles (audio tower + decoder)
+        sd = normalize_qwen_keys({k: v.detach().clone() for k, v in hf.state_dict().items()})
+        mel_lens = batch["feature_attention_mask"].sum(-1).tolist()
+        lsd = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}
+        worst = float("inf")
+        logits_by = {}
+        for tag, rnd in (("fp32", None), ("bf16", om.bf16_round)):
+            af, out_lens = om.qwen_audio_features(sd, batch["input_features"], mel_lens, cfg.audio.n_heads, rnd=rnd)
+            llm = om.LlamaOracle(lsd, cfg.llm.n_heads, cfg.llm.rms_eps, cfg.llm.rope_theta, rnd=rnd)
+            ids = batch["input_ids"][0, :prompt_len]
+            emb = llm.embed(ids)
+            emb[(ids == cfg.audio_token_id).nonzero().flatten()] = torch.cat([af[i, :n] for i, n in enumerate(out_lens)])
+            logits_by[tag] = llm.teacher_forced_logits(emb[None], torch.tensor([gen_ids]))[0]
+        lf, lb = logits_by["fp32"], logits_by["bf16"]
+        for t, tok in enumerate(gen_ids):
+            top2 = lf[t].topk(2)
+            if int(top2.indices[0]) != tok or int(lb[t].argmax()) != tok:
+                worst = -1.0
+                break
+            worst = min(worst, float(top2.values[0] - top2.values[1]) / max(float((lf[t] - lb[t]).abs().max()), 1e-6))
+        print(f"seed {seed}: ids {gen_ids}, smallest margin / bf16 distance = {worst:.1f}")
+        if worst > 12.0:
+            chosen = (seed, fwd, gen_ids, worst, prompt_len)
+            break
+    assert chosen is not None
+    seed, fwd, gen_ids, worst, prompt_len = chosen
+    save("qwen_glue_e2e.npz", weights_seed=seed, margin=worst, prompt_length=prompt_len, labels=fwd["labels"][0], loss=fwd["loss"],
+         logits_tail=fwd["logits"][0, -8:], gen_ids=torch.tensor(gen_ids))
+
+
 def g15_boundary():
     """The plugin boundary as the reference declares it: inspect.signature of BaseModel's public methods,
     ModelFactory's static methods, CustomSALMONN / CustomQwen constructors and entry points, and the action table of the
@@ -1479,3 +1552,4 @@ if __name__ == "__main__":
     g21_model_factory()
     g22_cli_end_to_end()
     g23_cli_end_to_end_speech()
+    g24_qwen_glue_end_to_end()

@@ -154,3 +154,36 @@ def test_audio_longer_than_30_seconds_is_truncated_like_the_feature_extractor(mo
     batch = {"input_ids": enc.input_ids[:, :prompt_len], "attention_mask": enc.attention_mask[:, :prompt_len],
              "input_features": enc.input_features, "feature_attention_mask": enc.feature_attention_mask}
     assert len(model.generate_output(batch)) == 1
+
+
+def test_reference_customqwen_glue_end_to_end():
+    """tests/golden/qwen_glue_e2e.npz: the REFERENCE's CustomQwen (unmodified) over HF Qwen2AudioForConditionalGeneration at the
+    `tiny` dims on CPU — `forward` (labels = -100 up to prompt_length, loss, logits) and `generate_output` (generate(max_new_tokens=10),
+    slice, decode).  This build's CustomQwen on the GPU, same weights (rebuilt from the seed: tests/golden/e2e_weights.py) and the
+    same batch dict: same labels, loss within the bf16 tolerance, and the same ten generated ids (tightest greedy margin 12x the
+    fp32-vs-bf16 oracle distance)."""
+    import os
+    import sys
+    from icl_speech_text_llm_amd.models.model_factory import ModelFactory
+    from icl_speech_text_llm_amd.runtime.qwen import normalize_qwen_keys
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, gold)
+    from e2e_weights import qwen_batch, tiny_qwen_hf_model
+    g = np.load(os.path.join(gold, "qwen_glue_e2e.npz"))
+    cfg, hf = tiny_qwen_hf_model(int(g["weights_seed"]))
+    model = ModelFactory.create_model("qwen2", device="cuda", arch="tiny", model_path="none", lora=False).eval()
+    sd = normalize_qwen_keys({k: v.detach().clone() for k, v in hf.state_dict().items()})
+    missing, unexpected = model.model.load_state_dict(sd, strict=False)
+    assert not [k for k in missing if "embed_positions" not in k] and not [k for k in unexpected if "embed_positions" not in k], (missing, unexpected)
+    batch, prompt_len = qwen_batch(cfg)
+    assert prompt_len == int(g["prompt_length"])
+    out = model.forward(dict(batch))
+    assert torch.equal(out["labels"][0].cpu(), torch.from_numpy(g["labels"]))
+    assert abs(float(out["loss"]) - float(g["loss"])) < 2e-2 * max(1.0, abs(float(g["loss"])))
+    r = _rel(out["logits"][0, -8:], torch.from_numpy(g["logits_tail"]))
+    print(f"reference CustomQwen.forward vs GPU: loss {float(g['loss']):.4f} / {float(out['loss']):.4f}, last-8 logits rel {r:.2e}")
+    assert r < 1e-2
+    gen_batch = {k: (v[:, :prompt_len] if k in ("input_ids", "attention_mask") else v) for k, v in batch.items()}
+    res = model.generate_ids(dict(gen_batch))
+    print("reference generate_output ids", g["gen_ids"].tolist(), "| GPU", res.tokens[0].tolist())
+    assert res.tokens[0].tolist() == g["gen_ids"].tolist()
