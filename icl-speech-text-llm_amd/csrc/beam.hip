@@ -23,6 +23,7 @@ constexpr int BEAM_TMAX = 64;    // max_new_tokens
 constexpr float BEAM_NEG = -1.0e9f;
 
 __device__ __forceinline__ bool lex_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+__device__ __forceinline__ float nan_to_neg_inf(float x) { return x == x ? x : -INFINITY; }
 
 __global__ __launch_bounds__(256) void beam_step_kernel(
     const float* __restrict__ logits, int64_t ldl, int rows_per_batch, int V, int K, int T, int step, int eos_id, int eos_id2, float rep_pen,
@@ -50,14 +51,15 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
   for (int k = 0; k < K; ++k) {
     const float* x = lbase + k * lstep;
     float m = -INFINITY;
-    for (int v = tid; v < V; v += 256) m = fmaxf(m, x[v]);
+    for (int v = tid; v < V; v += 256) m = fmaxf(m, nan_to_neg_inf(x[v]));     // fmaxf drops a NaN operand anyway; explicit
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane == 0) s_redv[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(s_redv[0], s_redv[1]), fmaxf(s_redv[2], s_redv[3]));
+    if (!(m > -INFINITY)) m = 0.f;                    // a row of NaN / -inf only: every log-probability becomes -inf below
     __syncthreads();
     float s = 0.f;
-    for (int v = tid; v < V; v += 256) s += expf(x[v] - m);
+    for (int v = tid; v < V; v += 256) s += expf(nan_to_neg_inf(x[v]) - m);
     for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) s_redv[wave] = s;
     __syncthreads();
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
       const float m = s_m[k], ls = s_ls[k], rs = s_rs[k];
       const float* x = lbase + k * lstep;
       for (int v = tid; v < V; v += 256) {
-        float lp = (x[v] - m) - ls;
+        const float xv = nan_to_neg_inf(x[v]);             // a NaN logit is a token that cannot be chosen, as in argmax_eos_kernel
+        float lp = xv > -INFINITY ? (xv - m) - ls : -INFINITY;
         if (penalised) {                                   // tokens of beam k's own sequence: x < 0 ? x * penalty : x / penalty
           bool seen = false;
           for (int t = 0; t < step; ++t) seen = seen || s_old_run[k * T + t] == v;
@@ -120,6 +123,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
         bv = s_redv[w];
         bi = s_redi[w];
       }
+    if (bi == 0x7fffffff) {       // nothing comparable was left (cannot happen once NaNs are mapped; kept so that parent /
+      bv = -INFINITY;             // next_ids stay inside [0, K) x [0, V) whatever the logits hold)
+      bi = r < V ? r : 0;
+    }
     if (tid == 0) {
       s_cv[r] = bv;
       s_ci[r] = bi;
@@ -215,13 +222,18 @@ __global__ __launch_bounds__(256) void beam_step_kernel(
 __global__ __launch_bounds__(256) void kv_copy_spans_kernel(
     const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, int64_t s_layer, int64_t s_seq, int64_t s_head,
     int64_t d_layer, int64_t d_seq, int64_t d_head, const int* __restrict__ src_seq, const int* __restrict__ src_t0,
-    const int* __restrict__ dst_seq, const int* __restrict__ dst_t0, const int* __restrict__ n_t, int n_fixed, int H, int D) {
+    const int* __restrict__ dst_seq, const int* __restrict__ dst_t0, const int* __restrict__ n_t, int n_fixed, int H, int D,
+    int src_n_seqs, int dst_n_seqs, int src_len, int dst_len) {
   const int r = blockIdx.x / H, h = blockIdx.x % H, l = blockIdx.y;
-  const int n = n_t ? n_t[r] : n_fixed;
-  const int64_t so = (int64_t)l * s_layer + (int64_t)(src_seq ? src_seq[r] : r) * s_seq + (int64_t)h * s_head +
-                     (int64_t)(src_t0 ? src_t0[r] : 0) * D;
-  const int64_t dof = (int64_t)l * d_layer + (int64_t)(dst_seq ? dst_seq[r] : r) * d_seq + (int64_t)h * d_head +
-                      (int64_t)(dst_t0 ? dst_t0[r] : 0) * D;
+  // sequence ids and span starts come from device state (the beam step's parent array): they are clamped to the arrays the
+  // caller described, so a corrupted id reads / writes a wrong but EXISTING span — never memory outside the allocation
+  const int ss = min(max(src_seq ? src_seq[r] : r, 0), src_n_seqs - 1);
+  const int ds = min(max(dst_seq ? dst_seq[r] : r, 0), dst_n_seqs - 1);
+  const int st0 = min(max(src_t0 ? src_t0[r] : 0, 0), src_len);
+  const int dt0 = min(max(dst_t0 ? dst_t0[r] : 0, 0), dst_len);
+  const int n = min(min(max(n_t ? n_t[r] : n_fixed, 0), src_len - st0), dst_len - dt0);
+  const int64_t so = (int64_t)l * s_layer + (int64_t)ss * s_seq + (int64_t)h * s_head + (int64_t)st0 * D;
+  const int64_t dof = (int64_t)l * d_layer + (int64_t)ds * d_seq + (int64_t)h * d_head + (int64_t)dt0 * D;
   const u32x4* sp = (const u32x4*)(src + so);
   u32x4* dp = (u32x4*)(dst + dof);
   const int chunks = n * D / 8;
@@ -260,8 +272,13 @@ extern "C" int icl_kv_copy_spans_bf16(const void* src, void* dst, int64_t src_la
                                       int64_t src_head_stride, int64_t dst_layer_stride, int64_t dst_seq_stride,
                                       int64_t dst_head_stride, const int32_t* src_seq, const int32_t* src_t0,
                                       const int32_t* dst_seq, const int32_t* dst_t0, const int32_t* n_t, int32_t n_fixed,
-                                      int32_t n_rows, int32_t n_layers, int32_t n_heads, int32_t head_dim, void* stream) {
+                                      int32_t n_rows, int32_t n_layers, int32_t n_heads, int32_t head_dim,
+                                      int32_t src_n_seqs, int32_t dst_n_seqs, int32_t src_len, int32_t dst_len, void* stream) {
   ICL_CHECK_ARG(src && dst, "icl_kv_copy_spans_bf16: NULL pointer");
+  ICL_CHECK_ARG(src_n_seqs > 0 && dst_n_seqs > 0 && src_len > 0 && dst_len > 0,
+                "icl_kv_copy_spans_bf16: src / dst extents (sequences, positions) must be > 0");
+  ICL_CHECK_ARG((src_seq || n_rows <= src_n_seqs) && (dst_seq || n_rows <= dst_n_seqs),
+                "icl_kv_copy_spans_bf16: n_rows=%d exceeds the %d / %d sequences of src / dst", n_rows, src_n_seqs, dst_n_seqs);
   ICL_CHECK_ARG(n_rows > 0 && n_layers > 0 && n_heads > 0 && head_dim > 0 && head_dim % 8 == 0,
                 "icl_kv_copy_spans_bf16: bad sizes (head_dim must be a multiple of 8)");
   ICL_CHECK_ARG(n_t || n_fixed >= 0, "icl_kv_copy_spans_bf16: n_fixed < 0");
@@ -273,7 +290,7 @@ extern "C" int icl_kv_copy_spans_bf16(const void* src, void* dst, int64_t src_la
   hipLaunchKernelGGL(kv_copy_spans_kernel, dim3(n_rows * n_heads, n_layers), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned short*)src, (unsigned short*)dst, src_layer_stride, src_seq_stride, src_head_stride,
                      dst_layer_stride, dst_seq_stride, dst_head_stride, src_seq, src_t0, dst_seq, dst_t0, n_t, n_fixed, n_heads,
-                     head_dim);
+                     head_dim, src_n_seqs, dst_n_seqs, src_len, dst_len);
   ICL_CHECK_LAUNCH("icl_kv_copy_spans_bf16");
   return ICL_OK;
 }

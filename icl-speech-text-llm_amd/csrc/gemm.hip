@@ -821,7 +821,9 @@ extern "C" int icl_gemm_rmsnorm_bf16(const icl_gemm_args* a, const float* gamma,
                 "icl_gemm_rmsnorm_bf16: N=%d must be a multiple of 4 and <= 8192, leading dimensions multiples of 4", a->N);
   ICL_CHECK_ARG(((uintptr_t)gamma & 15) == 0 && ((uintptr_t)xn & 7) == 0 && ((uintptr_t)a->C & 15) == 0 &&
                     (!a->R || ((uintptr_t)a->R & 15) == 0), "icl_gemm_rmsnorm_bf16: misaligned pointer");
-  if (a->split_k > 1) {
+  // the skinny kernels (tiles 4 / 6) split K inside the block and write the finished row themselves whatever split_k says:
+  // only a launch that really leaves split-K slabs behind takes the fused reduce + RMSNorm
+  if (a->split_k > 1 && a->tile != 4 && a->tile != 6) {
     const NormFuse nf{gamma, eps, (unsigned short*)xn, ld_xn};
     return gemm_impl(a, stream, nullptr, &nf);
   }

@@ -12,6 +12,10 @@
 //      ascending cumulative sum HF computes) is <= 1 - top_p, the largest one always stays;
 //   5. inverse-CDF draw over the kept candidates in that order with the caller's uniform u in [0,1);
 //   6. the same EOS / pad bookkeeping as the greedy tail (argmax_eos_kernel).
+// top_k == V is HF's "top-k switched off" (top_k = 0 / None in a generation config; TopKLogitsWarper clamps to V): the
+// probabilities are then normalised over the WHOLE row (one more pass), the candidate list holds the SAMPLE_CAP most likely
+// tokens and the nucleus cut works on "1 - mass before candidate j"; a nucleus wider than SAMPLE_CAP tokens is truncated to
+// them (a row that flat carries no label information; documented in include/icl_hip.h).
 // HBM-bound on 5 reads of one f32 logits row per sequence (L2 resident after the first); algorithmic bytes = 4*V per row.
 #include "common.h"
 
@@ -52,9 +56,10 @@ __global__ __launch_bounds__(256) void sample_eos_kernel(
   __syncthreads();
 
   // 2. radix select: key of the k-th largest score
+  const bool full = top_k >= V;                   // top-k off: candidates = the SAMPLE_CAP largest, full-row denominator
   if (tid == 0) {
     s_prefix = 0u;
-    s_remaining = (unsigned int)top_k;
+    s_remaining = (unsigned int)(full ? min(V, SAMPLE_CAP) : top_k);
     s_count = 0u;
   }
   for (int pass = 0; pass < 4; ++pass) {
@@ -127,6 +132,13 @@ __global__ __launch_bounds__(256) void sample_eos_kernel(
     cprob[i] = e;
     part += e;
   }
+  if (full) {                                     // every token of the row is in the distribution, listed or not
+    part = 0.0f;
+    for (int v = tid; v < V; v += 256) {
+      const float x = w[v];
+      part += x == x ? expf(x - top) : 0.0f;
+    }
+  }
   part = wave_reduce_sum(part);
   if ((tid & 63) == 0) red[tid >> 6] = part;
   __syncthreads();
@@ -137,7 +149,15 @@ __global__ __launch_bounds__(256) void sample_eos_kernel(
   // 5. nucleus cut + inverse-CDF draw (one thread: <= 1024 candidates, typically 50)
   if (tid == 0) {
     int keep = n_cand;
-    if (top_p < 1.0f) {
+    if (top_p < 1.0f && full) {                   // mass of candidates j.. (+ the unlisted tail) = 1 - mass before j
+      float before = cprob[0];
+      keep = 1;
+      for (int j = 1; j < n_cand; ++j) {
+        if (1.0f - before <= 1.0f - top_p) break;
+        before += cprob[j];
+        keep = j + 1;
+      }
+    } else if (top_p < 1.0f) {
       float tail = 0.0f;
       keep = 1;
       for (int j = n_cand - 1; j >= 1; --j) {
@@ -187,7 +207,8 @@ extern "C" int icl_sample_eos(const float* logits, int64_t ldl, int32_t B, int32
   ICL_CHECK_ARG(step >= 0 && step < out_stride, "icl_sample_eos: step=%d outside out_stride=%d", step, out_stride);
   ICL_CHECK_ARG(temperature > 0.0f, "icl_sample_eos: temperature must be > 0");
   ICL_CHECK_ARG(top_p > 0.0f && top_p <= 1.0f, "icl_sample_eos: top_p must be in (0,1]");
-  ICL_CHECK_ARG(top_k >= 1 && top_k <= SAMPLE_CAP && top_k <= V, "icl_sample_eos: top_k=%d must be in [1,%d] and <= V", top_k, SAMPLE_CAP);
+  ICL_CHECK_ARG(top_k >= 1 && (top_k <= SAMPLE_CAP || top_k == V) && top_k <= V,
+                "icl_sample_eos: top_k=%d must be in [1,%d] or equal to V=%d (top-k off)", top_k, SAMPLE_CAP, V);
   ICL_CHECK_ARG(repetition_penalty > 0.0f, "icl_sample_eos: repetition_penalty must be > 0");
   ICL_CHECK_ARG(n_prev == 0 || (prev_tokens && n_prev > 0 && n_prev <= prev_stride), "icl_sample_eos: bad prev_tokens");
   ICL_CHECK_ARG(!dbg_count || (dbg_ids && dbg_probs && dbg_cap > 0), "icl_sample_eos: incomplete debug outputs");

@@ -18,7 +18,8 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libicl_hip.so"))
 
 ICL_BF16, ICL_F32 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 1, 2, 4, 8
-ABI_VERSION = 4
+ABI_VERSION = 5
+SAMPLE_TOP_K_MAX = 1024      # SAMPLE_CAP of csrc/sampling.hip: candidate-list size of icl_sample_eos
 
 
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
@@ -83,7 +84,7 @@ _SIGNATURES = {
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "icl_kv_copy_spans_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                       c_void_p]),
+                                       c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "icl_logmel_whisper": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
                                    c_void_p, c_int64, c_void_p, c_void_p]),
     "icl_spec_to_xt": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
@@ -435,7 +436,8 @@ def kv_copy_spans(src, dst, n_rows: int, *, src_seq=None, src_t0=None, dst_seq=N
     _check(load_library().icl_kv_copy_spans_bf16(src.data_ptr(), dst.data_ptr(), src.stride(0), src.stride(1), src.stride(2),
                                                  dst.stride(0), dst.stride(1), dst.stride(2), _ptr(src_seq), _ptr(src_t0),
                                                  _ptr(dst_seq), _ptr(dst_t0), _ptr(n_t), n_fixed, n_rows, src.shape[0],
-                                                 src.shape[2], src.shape[4], _stream()), "icl_kv_copy_spans_bf16")
+                                                 src.shape[2], src.shape[4], src.shape[1], dst.shape[1], src.shape[3],
+                                                 dst.shape[3], _stream()), "icl_kv_copy_spans_bf16")
 
 
 def logmel_whisper(wav, wav_lens, mel_filters, n_mel: int, spec, xt, workspace):

@@ -64,6 +64,13 @@ class Workspace:
     def nbytes(self) -> int:
         return sum(e[0].numel() * e[0].element_size() for e in self._bufs.values())
 
+    def release(self, *names: str) -> None:
+        """Drop the named buffers (re-created on demand).  A graph-visible name counts as a move."""
+        for key in [k for k in self._bufs if k[0] in names]:
+            del self._bufs[key]
+            if key[0].startswith(self.GRAPH_VISIBLE):
+                self.generation += 1
+
     def clear(self) -> None:
         """Drop every buffer (they are re-created on demand).  Counts as a move: captured graphs are retired."""
         self._bufs.clear()

@@ -230,8 +230,16 @@ class CausalLMRuntimeMixin:
         nxt = ws.get("gen_next", (Bn,), I32)
         sampled = do_sample or repetition_penalty != 1.0
         if sampled:
-            # HF's TopKLogitsWarper clamps top_k to the vocabulary; 0 / None switch it off (= every token a candidate)
+            # HF's TopKLogitsWarper clamps top_k to the vocabulary; 0 / None switch it off.  The kernel takes 1..SAMPLE_TOP_K_MAX, or
+            # the vocabulary size for "off" (full-row normalisation, nucleus over the 1024 most likely tokens); anything else is
+            # a caller's argument error and is refused HERE, before a launch — never as a device-side failure
             top_k = c.vocab if not top_k else min(int(top_k), c.vocab)
+            if top_k < 1 or B.SAMPLE_TOP_K_MAX < top_k < c.vocab:
+                raise ValueError(f"top_k={top_k}: the sampling kernel supports 1..{B.SAMPLE_TOP_K_MAX}, or 0 / None / >= vocabulary "
+                                 f"({c.vocab}) for no top-k filter")
+            if (do_sample and not (0.0 < float(top_p) <= 1.0 and float(temperature) > 0.0)) or not float(repetition_penalty) > 0.0:
+                raise ValueError(f"sampling knobs out of range: temperature={temperature} (> 0), top_p={top_p} (0 < p <= 1), "
+                                 f"repetition_penalty={repetition_penalty} (> 0)")
             knobs = ((float(temperature), top_k, float(top_p)) if do_sample else (1.0, 1, 1.0)) + (float(repetition_penalty),)
             uni = ws.get("gen_uniform", (max_new_tokens, Bn), F32)
             if do_sample and generator is not None and generator.device.type != uni.device.type:
@@ -382,8 +390,8 @@ class CausalLMRuntimeMixin:
             pos_all.copy_(torch.tensor([[s + t for s in lens_rep] for t in range(steps)], dtype=I32), non_blocking=True)
             len_all.copy_(torch.tensor([[s + t + 1 for s in lens_rep] for t in range(steps)], dtype=I32), non_blocking=True)
             sid.copy_(torch.arange(BK, dtype=I32), non_blocking=True)
-            tmp_k = ws.get("gen_beam_tmp_k", (c.n_layers, BK, c.n_heads, steps, c.head_dim), BF16)
-            tmp_v = ws.get("gen_beam_tmp_v", tuple(tmp_k.shape), BF16)
+            tmp_k = ws.get("beam_tmp_k", (c.n_layers, BK, c.n_heads, steps, c.head_dim), BF16)
+            tmp_v = ws.get("beam_tmp_v", tuple(tmp_k.shape), BF16)
             for t in range(steps):
                 if t:                                          # the t positions generated so far follow their beam's parent
                     for kv, tmp in ((cache.k, tmp_k), (cache.v, tmp_v)):
@@ -393,6 +401,7 @@ class CausalLMRuntimeMixin:
                 score(lg, t + 1)
         best = st.fin_seq[:, 0].cpu().to(torch.int64)                                   # the only D2H pair of the call
         blen = st.fin_len[:, 0].cpu()
+        ws.release("beam_tmp_k", "beam_tmp_v")      # 2 x layers x rows x heads x (T-1) x head_dim bf16: not kept between calls
         width = max(1, int(blen.max()))
         return GenerateResult(tokens=best[:, :width].contiguous(), first_logits=first)
 

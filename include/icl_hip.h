@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ICL_ABI_VERSION 4
+#define ICL_ABI_VERSION 5
 
 /* error codes */
 #define ICL_OK 0
@@ -235,7 +235,9 @@ int icl_argmax_eos(const float* logits, int64_t ldl, int32_t B, int32_t V, int32
  * all divided by temperature; candidates = scores >= the top_k-th largest score (ties kept); probabilities = softmax over
  * the candidates sorted by (score desc, token asc); candidate j is dropped when the mass of candidates j.. is <= 1-top_p
  * (the largest always stays); the token is the first kept candidate whose running mass exceeds uniforms[b] * kept mass.
- * Then exactly icl_argmax_eos's bookkeeping.  work f32 [B][ldw>=V] is scratch; top_k in [1,1024]; greedy search with a
+ * Then exactly icl_argmax_eos's bookkeeping.  work f32 [B][ldw>=V] is scratch; top_k in [1,1024], or top_k == V = "top-k
+ * off" (HF: top_k 0 / None): probabilities are then normalised over the whole row, candidates are the 1024 most likely
+ * tokens and a nucleus wider than that is truncated to them; any other top_k is ICL_EINVAL.  Greedy search with a
  * repetition penalty is top_k = 1.  Optional debug outputs (NULL to skip): the kept tokens, their renormalised
  * probabilities and their count, dbg_cap entries per sequence.
  * Replaces HF generate(do_sample=True, temperature, top_p, repetition_penalty) as called at models/custom_salmon.py:705-721
@@ -341,8 +343,12 @@ int icl_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, fl
  *   num_beams, length_penalty) at models/custom_salmon.py:704-715 (per-task values: models/multi_task_model.py:142).
  * icl_kv_copy_spans_bf16: for every layer l < n_layers, head h < n_heads and row r < n_rows, copy n (= n_t[r], or n_fixed when
  *   n_t is NULL) positions of head_dim bf16 from src[l][src_seq[r]][h][src_t0[r] ..] to dst[l][dst_seq[r]][h][dst_t0[r] ..]
- *   (NULL seq array = r, NULL t0 array = 0; strides in elements).  src and dst spans must not overlap.  Stands in for HF's
+ *   (NULL seq array = r, NULL t0 array = 0; strides in elements).  src and dst spans must not overlap.  src / dst hold
+ *   src_n_seqs / dst_n_seqs sequences of src_len / dst_len positions: ids, starts and counts read from device memory are
+ *   clamped to those extents (ABI 5), so a corrupted parent id copies a wrong span, never out of bounds.  Stands in for HF's
  *   cache.reorder_cache(beam_idx): only the positions after the prompt differ between the beams of a row.
+ *   icl_beam_step treats a NaN logit as -inf (a token that cannot be chosen; icl_argmax_eos does the same), so parent[]
+ *   always names a beam of its own row.
  */
 int icl_beam_step(const float* logits, int64_t ldl, int32_t rows_per_batch, int32_t B, int32_t V, int32_t num_beams,
                   int32_t max_new_tokens, int32_t step, int32_t eos_id, int32_t eos_id2, float length_penalty,
@@ -353,7 +359,8 @@ int icl_kv_copy_spans_bf16(const void* src, void* dst, int64_t src_layer_stride,
                            int64_t src_head_stride, int64_t dst_layer_stride, int64_t dst_seq_stride,
                            int64_t dst_head_stride, const int32_t* src_seq, const int32_t* src_t0,
                            const int32_t* dst_seq, const int32_t* dst_t0, const int32_t* n_t, int32_t n_fixed,
-                           int32_t n_rows, int32_t n_layers, int32_t n_heads, int32_t head_dim, void* stream);
+                           int32_t n_rows, int32_t n_layers, int32_t n_heads, int32_t head_dim,
+                           int32_t src_n_seqs, int32_t dst_n_seqs, int32_t src_len, int32_t dst_len, void* stream);
 
 /* ---- K12: causal-LM cross entropy (teacher-forced forward only) -------------------------------
  * row_loss[r] = logsumexp(logits[r][:]) - logits[r][labels[r]] for labels[r] in [0,V), else 0;

@@ -788,12 +788,14 @@ def test_gemm_m128_decode_kernel(B, M, N, K, split):
 
 
 @pytest.mark.parametrize("M,N,K,split,tile", [(256, 4096, 1024, 8, 5), (130, 4096, 2048, 4, 5), (37, 5120, 1024, 2, 5), (256, 4096, 512, 1, 5),
-                                              (300, 4096, 1024, 4, 2), (5, 4096, 1024, 1, 6)])
+                                              (300, 4096, 1024, 4, 2), (5, 4096, 1024, 1, 6), (5, 4096, 1024, 2, 6), (33, 4096, 1024, 4, 4)])
 def test_gemm_rmsnorm_decode_fusion(B, M, N, K, split, tile):
     """icl_gemm_rmsnorm_bf16 (decode: projection back into the residual stream + the RMSNorm that follows, the split-K
     reduction, residual add, row store and normalisation in ONE kernel): the f32 row must be bit-identical to icl_gemm_bf16
     with the same split, the normalised row equal to icl_rmsnorm of it up to the summation order of its sum of squares
-    (fixed, but four wave sums instead of one wave per row: <= 1 bf16 ulp on a few elements), in place over the residual."""
+    (fixed, but four wave sums instead of one wave per row: <= 1 bf16 ulp on a few elements), in place over the residual.
+    split > 1 on the skinny tiles (4 / 6): those kernels split K inside the block and leave no slabs — the entry point must then
+    run the plain norm after the GEMM instead of returning with xn unwritten (advisor finding, round 3)."""
     a, w = _rand_bf16(M, K, seed=171, scale=0.5), _rand_bf16(N, K, seed=172, scale=0.05)
     res = torch.randn(M, N, device=DEV)
     gamma = 1.0 + 0.1 * torch.randn(N, device=DEV)
@@ -910,6 +912,32 @@ def test_sample_eos_matches_oracle_and_hf_golden():
     assert nxt.tolist() == [7, top] and fin.tolist() == [1, 1]
 
 
+def test_sample_eos_without_top_k_normalises_over_the_whole_row():
+    """top_k == V = HF's "top-k off" (top_k 0 / None; TopKLogitsWarper clamps to the vocabulary): the kept set and its
+    probabilities must be HF's top-p over the WHOLE distribution whenever the nucleus fits the kernel's 1024-entry candidate
+    list; a small vocabulary fits whatever top_p is (incl. 1.0 = the full softmax)."""
+    from oracle import models as om
+    g = torch.Generator().manual_seed(11)
+    for V, temp, p, pen, scale in ((777, 1.0, 1.0, 1.0, 2.0), (777, 0.7, 0.6, 1.2, 2.0), (32001, 0.8, 0.9, 1.0, 6.0), (156032, 0.7, 0.5, 1.1, 8.0)):
+        Bn, step = 4, 5
+        logits = torch.randn(Bn, V, generator=g) * scale
+        prev = torch.randint(0, V, (Bn, 16), generator=g)
+        u = torch.rand(Bn, generator=g)
+        toks, nxt, fin, (ids, probs, cnt) = _sample_case(logits, prev, step, temp, V, p, pen, u)
+        for b in range(Bn):
+            oi, op = om.sample_filter(logits[b].numpy(), prev[b, :step].tolist(), pen, temp, V, p)
+            assert len(oi) <= 1000, "test case must keep the nucleus inside the candidate list"
+            n = int(cnt[b])
+            assert abs(n - len(oi)) <= 1, (V, b, n, len(oi))          # the cut sums the mass from the other end than HF does
+            m = min(n, len(oi))
+            assert ids[b, :m].tolist() == oi[:m].tolist(), (V, b)
+            if n == len(oi):
+                assert float((probs[b, :n] - torch.from_numpy(op)).abs().max()) < 2e-6, (V, b)
+            assert int(nxt[b]) in ids[b, :n].tolist()
+    with pytest.raises(Exception):                                    # between the candidate-list size and V: an argument error
+        _sample_case(torch.randn(1, 32001), torch.zeros(1, 16, dtype=torch.long), 0, 1.0, 2000, 0.9, 1.0, torch.zeros(1))
+
+
 # ---- beam search: the step kernel against the oracle's scorer, the span copy against indexing -----------------------------------
 @pytest.mark.parametrize("Bn,K,V,T,lp,eos", [(3, 4, 260, 6, 1.0, 17), (2, 8, 32001, 5, 2.0, 2), (5, 1, 40, 4, 0.0, 3),
                                               (2, 3, 1000, 64, -1.0, 5), (1, 2, 4, 3, 1.0, 0), (3, 4, 300, 6, 1.0, (17, 40)),
@@ -964,6 +992,53 @@ def test_beam_step_matches_oracle_scorer(B, Bn, K, V, T, lp, eos, pen):
     for b in range(Bn):
         assert state.fin_seq[b, 0, :int(n[b])].cpu().tolist() == [t for t in want[b].tolist()][:int(n[b])]
     assert torch.allclose(state.fin_score[:, 0].cpu(), score, rtol=2e-5, atol=2e-5)
+
+
+def test_beam_step_with_nan_logits_keeps_parents_inside_the_row(B):
+    """A NaN logit is a token that cannot be chosen (as in icl_argmax_eos); a row of nothing but NaN still yields parents inside
+    [b*K, b*K+K) and tokens inside [0, V) — `parent` feeds icl_kv_copy_spans_bf16 as a sequence id (advisor finding, round 3)."""
+    Bn, K, V, T = 3, 4, 500, 4
+    st = B.BeamState(lambda name, shape, dt: torch.empty(shape, dtype=dt, device=DEV), Bn, K, T, pad_id=0)
+    g = torch.Generator().manual_seed(3)
+    lg = torch.randn(Bn, V, generator=g)
+    lg[0, 17] = float("nan")                    # one NaN among good logits
+    lg[1, :] = float("nan")                     # a whole row of NaN
+    B.beam_step(lg.to(DEV), st, 0, 2, 1.0)
+    for step in (1, 2):
+        lgk = torch.randn(Bn * K, V, generator=g)
+        lgk[0:K, 33] = float("nan")
+        lgk[K + 1, :] = float("nan")            # one beam of row 1 is all NaN
+        lgk[2 * K:3 * K, :] = float("nan")      # every beam of row 2
+        B.beam_step(lgk.to(DEV), st, step, 2, 1.0)
+        par, nxt = st.parent.cpu().view(Bn, K), st.next_ids.cpu().view(Bn, K)
+        for b in range(Bn):
+            assert bool(((par[b] >= b * K) & (par[b] < b * K + K)).all()), (step, b, par[b])
+            assert bool(((nxt[b] >= 0) & (nxt[b] < V)).all()), (step, b, nxt[b])
+        assert 33 not in nxt[0].tolist()
+    assert 17 not in st.run_seq.cpu()[0, :, 0].tolist()
+    # the same first step with the NaN replaced by a hopeless finite logit: row 0's choices are the same
+    st2 = B.BeamState(lambda name, shape, dt: torch.empty(shape, dtype=dt, device=DEV), Bn, K, T, pad_id=0)
+    lg2 = lg.clone()
+    lg2[0, 17] = -1e30
+    st3 = B.BeamState(lambda name, shape, dt: torch.empty(shape, dtype=dt, device=DEV), Bn, K, T, pad_id=0)
+    B.beam_step(lg2.to(DEV), st2, 0, 2, 1.0)
+    B.beam_step(lg.to(DEV), st3, 0, 2, 1.0)
+    assert torch.equal(st2.next_ids.cpu()[:K], st3.next_ids.cpu()[:K])
+
+
+def test_kv_copy_spans_clamps_corrupt_ids(B):
+    """Sequence ids / starts / counts read from device memory are clamped to the extents the caller described (ABI 5)."""
+    L, S, H, P, D = 2, 4, 2, 8, 64
+    src = torch.randn(L, S, H, P, D, device=DEV).to(torch.bfloat16)
+    dst = torch.zeros(L, S, H, P, D, dtype=torch.bfloat16, device=DEV)
+    guard = torch.zeros(1 << 16, dtype=torch.bfloat16, device=DEV)      # noqa: F841 (keeps a neighbour allocation alive)
+    bad = torch.tensor([0x7fffffff // 500, -5, 2, 3], dtype=torch.int32, device=DEV)
+    n_t = torch.tensor([3, 100, 2, -1], dtype=torch.int32, device=DEV)
+    B.kv_copy_spans(src, dst, 4, src_seq=bad, n_t=n_t)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, 0, :, :3], src[:, S - 1, :, :3])          # id clamped to the last sequence
+    assert torch.equal(dst[:, 1], src[:, 0])                            # id clamped to 0, count clamped to the 8 positions
+    assert torch.equal(dst[:, 2, :, :2], src[:, 2, :, :2]) and not bool(dst[:, 3].any())
 
 
 def test_beam_step_rejects_bad_arguments(B):

@@ -547,6 +547,22 @@ def test_generate_edge_cases(env):
     sampled = rt.generate(prompts[1:], None, max_new_tokens=2, do_sample=True, top_k=100000, top_p=0.9,
                           generator=torch.Generator(device=DEV).manual_seed(1))      # HF clamps top_k to the vocabulary
     assert sampled.tokens.shape[0] == 2
+    # top_k = 0 / None is HF's "no top-k filter" (a generation_config.json may say so): it must run, and give the same draws as
+    # any top_k >= vocabulary; a top_k between the kernel's candidate-list size and the vocabulary is an ARGUMENT error raised
+    # before any launch (ValueError: the CLI logs and skips the batch) — never a device-side IclError (advisor finding, round 3)
+    V = cfg.llama.vocab
+    outs = [rt.generate(prompts[1:], None, max_new_tokens=3, do_sample=True, top_k=k, top_p=0.8, temperature=0.9,
+                        generator=torch.Generator(device=DEV).manual_seed(4)).tokens for k in (0, None, V, 10 * V)]
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    from icl_speech_text_llm_amd.runtime import binding as Bd
+    if V > Bd.SAMPLE_TOP_K_MAX + 1:
+        with pytest.raises(ValueError, match="top_k"):
+            rt.generate(prompts[1:], None, max_new_tokens=3, do_sample=True, top_k=Bd.SAMPLE_TOP_K_MAX + 1)
+    with pytest.raises(ValueError, match="top_k"):
+        rt.generate(prompts[1:], None, max_new_tokens=3, do_sample=True, top_k=-3)
+    with pytest.raises(ValueError, match="sampling knobs"):
+        rt.generate(prompts[1:], None, max_new_tokens=3, do_sample=True, temperature=0.0)
+    assert rt.generate(prompts[1:], None, max_new_tokens=2, suppress_eos=True).tokens.shape == (2, 2)      # still usable
 
 
 def test_encode_speech_edge_lengths(env):
