@@ -102,10 +102,12 @@ def parse():
                          "ModelFactory -> SalmonProcessor / DataLoader -> generate_output (H2D, tokenisation, batch_decode inside "
                          "the timed region; SURVEY.md §8d)")
     ap.add_argument("--no-through-plugin", action="store_true", help="skip the plugin-path leg")
-    ap.add_argument("--plugin-workers", type=int, default=8)
+    ap.add_argument("--plugin-workers", type=int, default=8, help="item-pipeline workers of the plugin-path leg (capped at cores per rank - 1)")
+    ap.add_argument("--plugin-rows", type=int, default=0, help="distinct clips in the on-disk dataset of the plugin-path leg (default min(256, batch))")
     ap.add_argument("--plugin-batch", type=int, default=None, help="batch size of the plugin-path leg (default: --batch, the micro-batch of the runtime number)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the BASELINE.json configs 4 and 5 (1-GPU halves) that the default N = 1 run appends after the headline legs")
+    ap.add_argument("--other-batch", type=int, default=128, help="micro-batch of the configs 4 / 5 legs")
     ap.add_argument("--workload", default="c2", choices=["c2", "c2s", "c4", "c5"],
                     help="BASELINE.md §4: c2 = headline (default); c2s = 5 speech exemplars; c4 = Qwen2-Audio HVB; "
                          "c5 = Llama2-13B VOXCELEB+HVB+VOXPOPULI round-robin")
@@ -141,6 +143,38 @@ WORKLOADS = {   # name -> (description, text tokens per utterance (round-robin l
     "c4": ("C4: Qwen2-Audio-7B speech_only 5-shot HVB", [514], 1),
     "c5": ("C5: SALMONN Llama2-13B, VOXCELEB+HVB+VOXPOPULI round-robin, 5 text exemplars", [288, 512, 320], 1),
 }
+
+
+GEMM_KERNEL_NAMES = {1: "gemm_bf16_kernel<2,2,4,4> (128x128x64 tile)", 2: "gemm_bf16_kernel<2,2,2,2> (64x64x64 tile)",
+                     3: "gemm256_bf16_kernel (256x256x64 rolling LDS-DMA pipeline)", 4: "gemm_skinny_kernel (decode, <= 8 rows)",
+                     5: "gemm_m128_kernel (decode, 9..256 rows, decode-packed weights)", 6: "gemm_skinny_kernel (decode-packed weights)"}
+TFLOP_PER_UTT = {"c2": 7.68, "c2s": 25.6, "c4": 19.2, "c5": 14.7}      # SURVEY.md §8d / BASELINE.md §4
+
+
+def gemm_event_summary(profile, elapsed: float):
+    """Live HIP-event timings of every GEMM launch of the timed region -> (dominant tile id, {tile: (flops, seconds, launches)})."""
+    per_tile = {}
+    for (tile, sk, f, e0, e1, shape) in profile:
+        fl, tt, n = per_tile.get(tile, (0.0, 0.0, 0))
+        per_tile[tile] = (fl + f, tt + e0.elapsed_time(e1) * 1e-3, n + 1)
+    dom = max(per_tile, key=lambda k: per_tile[k][1])          # dominant kernel = largest share of GPU time
+    return dom, per_tile
+
+
+def workload_roofline(wl: str, utt_per_s: float, profile, elapsed: float):
+    """The per-config roofline block of the non-headline workloads: whole-utterance MFMA fraction from the §8d FLOP count and
+    the dominant GEMM kernel's own fraction from the live events of the timed steps."""
+    tf = TFLOP_PER_UTT[wl]
+    out = {"bound": "mfma", "tflop_per_utterance": tf, "achieved": round(utt_per_s * tf, 1), "peak": PEAK_BF16_TFLOPS,
+           "unit": "TFLOP/s", "frac": round(utt_per_s * tf / PEAK_BF16_TFLOPS, 4), "mfma_roof_utt_per_s": round(PEAK_BF16_TFLOPS / tf, 1)}
+    if profile:
+        dom, per_tile = gemm_event_summary(profile, elapsed)
+        fl, tt, n = per_tile[dom]
+        out["dominant_kernel"] = {"kernel": GEMM_KERNEL_NAMES.get(dom, str(dom)), "achieved": round(fl / tt / 1e12, 1),
+                                  "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4), "launches": n,
+                                  "avg_launch_us": round(tt / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
+                                  "share_of_step_time": round(tt / elapsed, 3)}
+    return out
 
 
 def synth_utterances(first: int, count: int, vocab: int):
@@ -386,45 +420,49 @@ def _median(xs):
     return xs[len(xs) // 2] if xs else None
 
 
-def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batches: int = 5, warm: int = 2, make_model=None,
-                   workers=None):
-    """ModelFactory.create_model -> SalmonProcessor -> DataLoader(num_workers) -> model.generate_ids / decode_ids, timed the way
-    the reference's loop counts examples (inference/inference.py:259-266,301-368; utils/performance_utils.py:96-122): H2D of the
-    raw waveforms, the host prompt split + tokenisation, K1..K11 and batch_decode are all inside the timed region.
+def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batches=None, warm: int = 2, make_model=None,
+                   workers=None, gpu_rate=None):
+    """ModelFactory.create_model -> on-disk HF folder -> load_dataset -> DatasetFactory / InferenceDataset -> SalmonProcessor ->
+    ArenaBatchLoader(num_workers) -> model.generate_ids / decode_ids, timed the way the reference's loop counts examples
+    (inference/inference.py:259-266,301-368; utils/performance_utils.py:96-122): the item pipeline (Arrow row -> few-shot prompt
+    -> tokenizer -> float32 waveform), collation, H2D of the raw waveforms, the host prompt split + tokenisation, K1..K11 and
+    batch_decode are all inside the timed region.
 
-    ``world > 1``: EVERY rank runs this leg on its own shard (dataset index i = rank mod world) with its own DataLoader
-    workers, and every batch ends with the ONE fixed-shape all_gather_into_tensor of (index, ids, length, bf16 first-step
-    logits) — the whole per-rank host pipeline whose feed rate decides the 8-GPU scaling (8 ranks x ~140 utt/s x
-    1.9 MB of audio), bracketed by barriers, MAX over ranks.  Rank 0 returns the whole-node rate plus each rank's
-    generate / between-batches times and host-only DataLoader ceiling; the other ranks return None."""
-    from torch.utils.data import DataLoader, Subset
+    LENGTH: the loader keeps ``workers + 2`` batches in flight, so a short run is fed from its start-up burst and says nothing
+    about the host keeping up.  The timed region is therefore >= 30 s of GPU work and >= twice that depth
+    (``n_batches`` = max(30 s x gpu_rate / batch, 2 x (workers + 2) + 2)), and ``host_ceiling_utt_per_s`` is the SAME loader
+    run host-only (no model, no device) over the same number of batches after its own warm-up wave — a steady-state rate.
+    ``host_bound`` = ceiling < 1.5 x the GPU-side rate.
+
+    ``world > 1``: EVERY rank runs this leg on its own shard (dataset index i = rank mod world) with its own workers, and every
+    batch ends with the ONE fixed-shape all_gather_into_tensor of (index, ids, length, bf16 first-step logits), bracketed by
+    barriers, MAX over ranks.  Rank 0 returns the whole-node rate plus each rank's figures; the other ranks return None."""
+    import math
+    import shutil
+    import tempfile
+    from torch.utils.data import Subset
+    from icl_speech_text_llm_amd.data.dataset_factory import DatasetFactory
     from icl_speech_text_llm_amd.data.model_processors import get_processor
-    from icl_speech_text_llm_amd.data.synthetic_dataset import SyntheticICLDataset
-    from icl_speech_text_llm_amd.data.task_configs import DatasetType
+    from icl_speech_text_llm_amd.data.synthetic_dataset import write_voxceleb_folder_arrow
+    from icl_speech_text_llm_amd.data.task_configs import DatasetType, set_dataset_root
     from icl_speech_text_llm_amd.models.model_factory import ModelFactory
     from icl_speech_text_llm_amd.runtime import dp
-    from icl_speech_text_llm_amd.utils.data_utils import device_prefetch
+    from icl_speech_text_llm_amd.utils.batch_loader import ArenaBatchLoader
+    from icl_speech_text_llm_amd.utils.data_utils import clear_dataset_cache, load_dataset
     from icl_speech_text_llm_amd.utils.performance_utils import PerformanceTracker
     dev = torch.device(dev)
     on_gpu = dev.type == "cuda"
     bs = args.plugin_batch or args.batch
     workers = args.plugin_workers if workers is None else workers
+    depth = workers + 2
+    if n_batches is None:
+        n_batches = max(int(math.ceil(30.0 * (gpu_rate or 145.0) / bs)), 2 * depth + 2)
     if make_model is None:
         model = ModelFactory.create_model("salmonn", device=str(dev), arch="tiny" if args.tiny else "7b", low_resource=True,
                                           llama_path="stand-in:subword", ckpt_path="", lora_alpha=32).eval()
     else:
         model = make_model()
     proc = get_processor("salmonn", model.input_processor, model.llama_tokenizer)
-    # one batch more than is consumed: the loop below stops before the loader is exhausted, so that tearing the DataLoader's
-    # workers down (~0.3 s, once per epoch) does not land between two timed batches of a five-batch measurement
-    per_rank = bs * (n_batches + warm + 1)
-    ds = SyntheticICLDataset(proc, [DatasetType.VOXCELEB], n_items=per_rank * world, num_examples=5,
-                             input_mode="speech_only", fewshot_mode="text", audio_seconds=getattr(args, "plugin_audio_seconds", 30.0))
-    shard = dp.shard_indices(len(ds), rank, world)
-
-    def loader():
-        return DataLoader(Subset(ds, shard) if world > 1 else ds, batch_size=bs, shuffle=False, num_workers=workers,
-                          pin_memory=on_gpu, collate_fn=proc.collate_batch, persistent_workers=False)
 
     def sync():
         if on_gpu:
@@ -434,15 +472,34 @@ def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batche
         if world > 1:
             dist.barrier()
         sync()
-    # host ceiling: this rank's DataLoader alone (item synthesis stands in for disk reads + resampling of the real datasets);
-    # all ranks at once, as in the timed loop: the host cores are shared
+    # ---- the dataset: an HF folder on local disk, read by the reference-compatible item pipeline ---------------------------
+    secs = float(getattr(args, "plugin_audio_seconds", 30.0))
+    n_rows = int(getattr(args, "plugin_rows", 0)) or min(256, max(bs, 8))      # distinct clips on disk; the run cycles through them
+    root = os.environ.get("ICL_BENCH_DATA_ROOT") or os.path.join(tempfile.gettempdir(), f"icl_bench_data_{os.getuid()}_{n_rows}x{secs:g}s")
+    t_write = time.perf_counter()
+    if rank == 0:
+        write_voxceleb_folder_arrow(root, n_rows, seconds=secs)
     barrier()
-    t0, n_host = time.perf_counter(), 0
-    for b_i, batch in enumerate(loader()):
+    set_dataset_root(root)
+    clear_dataset_cache()
+    rows = load_dataset(DatasetType.VOXCELEB, split="test")
+    t_write = time.perf_counter() - t_write
+    items = DatasetFactory.create_dataset(DatasetType.VOXCELEB, rows, proc, is_training=False, input_mode="speech_only",
+                                          fewshot_mode="text", num_examples=5)
+    per_rank = bs * (n_batches + warm)
+    shard = dp.shard_indices(per_rank * world, rank, world)                    # i = rank (mod world), as the CLI shards
+    ds = Subset(items, [i % len(items) for i in shard])
+
+    # ---- host ceiling: the loader alone, host-only, steady state --------------------------------------------------------------
+    barrier()
+    host = ArenaBatchLoader(ds, bs, proc.collate_batch, num_workers=workers, device="cpu")
+    stamps, n_host = [], 0
+    for batch in host:
         n_host += len(batch["prompt"])
-        if b_i + 1 >= max(2, n_batches // 2):
-            break
-    host_rate = n_host / (time.perf_counter() - t0)
+        stamps.append(time.perf_counter())
+    host.close()
+    skip = min(depth, max(0, len(stamps) - 2))               # the first wave was produced in parallel before anything was consumed
+    host_rate = (len(stamps) - 1 - skip) * bs / max(stamps[-1] - stamps[skip], 1e-9)
     vocab = len(model.llama_tokenizer)
     if world > 1:
         packer = dp.result_packer(NEW_TOKENS, vocab)
@@ -451,62 +508,74 @@ def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batche
         row_all = torch.empty(world * bs, packer.row_bytes, dtype=torch.uint8, device=cdev)
     tracker, done, prompt_tokens, stages, gaps, t_prev_end, t_start, t_end = None, 0, [], [], [], None, None, None
     pad_id, eos_id = model.llama_tokenizer.pad_token_id, model.llama_tokenizer.eos_token_id
-    with torch.no_grad():
-        for b_i, batch in enumerate(device_prefetch(loader(), dev)):      # as the CLI does: batch i+1's H2D under batch i's kernels
-            if b_i == warm:
-                barrier()
-                tracker, t_start, t_prev_end = PerformanceTracker(log_interval=10 ** 9), time.perf_counter(), None
-            batch["max_new_tokens"] = NEW_TOKENS
-            t1 = time.perf_counter()
-            if t_prev_end is not None and tracker is not None:
-                gaps.append(round((t1 - t_prev_end) * 1e3, 1))
-            n_b = len(batch["prompt"])
-            if world > 1:      # the data-parallel CLI's per-batch work: ids + logits as tensors, rank-local decode, one gather
-                res = model.generate_ids(batch, want_first_logits=True)
-                out = model.decode_ids(res.tokens)
-                ids = torch.full((n_b, NEW_TOKENS), pad_id, dtype=torch.int32)
-                ids[:, :res.tokens.shape[1]] = res.tokens.to(torch.int32)
-                is_eos = res.tokens == eos_id
-                glen = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((n_b,), res.tokens.shape[1])).to(torch.int32)
-                idx = torch.tensor(shard[b_i * bs: b_i * bs + n_b], dtype=torch.int64)
-                packer.pack(row_local, index=idx, gen_ids=ids, gen_len=glen, first_logits=res.first_logits)
-                dp.all_gather_rows(dist, row_local, out=row_all)
-            else:
-                out = model.generate_output(batch)
-            t_prev_end = time.perf_counter()
-            if tracker is not None:
-                tracker.update(t_prev_end - t1, n_b)
-                done += len(out)
-                st = dict(getattr(model, "last_stage_seconds", {}), total=t_prev_end - t1)
-                stages.append({k: round(v * 1e3, 1) for k, v in st.items()})
-            if b_i == 0:
-                prompt_tokens = [len(model.llama_tokenizer(p, add_special_tokens=False)["input_ids"]) for p in batch["prompt"][:4]]
-            if b_i + 1 >= warm + n_batches:
-                barrier()
-                t_end = time.perf_counter()        # before the break: leaving the loop finalises the prefetcher and with it the
-                last_b = b_i                       # DataLoader's workers
-                break
+    loader = ArenaBatchLoader(ds, bs, proc.collate_batch, num_workers=workers, device=dev)
+    last_b = 0
+    try:
+        with torch.no_grad():
+            for b_i, batch in enumerate(loader):       # as the CLI does: batch i+1 collated and copied under batch i's kernels
+                if b_i == warm:
+                    barrier()
+                    tracker, t_start, t_prev_end = PerformanceTracker(log_interval=10 ** 9), time.perf_counter(), None
+                batch["max_new_tokens"] = NEW_TOKENS
+                t1 = time.perf_counter()
+                if t_prev_end is not None and tracker is not None:
+                    gaps.append(round((t1 - t_prev_end) * 1e3, 1))
+                n_b = len(batch["prompt"])
+                if world > 1:      # the data-parallel CLI's per-batch work: ids + logits as tensors, rank-local decode, one gather
+                    res = model.generate_ids(batch, want_first_logits=True)
+                    out = model.decode_ids(res.tokens)
+                    ids = torch.full((n_b, NEW_TOKENS), pad_id, dtype=torch.int32)
+                    ids[:, :res.tokens.shape[1]] = res.tokens.to(torch.int32)
+                    is_eos = res.tokens == eos_id
+                    glen = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((n_b,), res.tokens.shape[1])).to(torch.int32)
+                    idx = torch.tensor(shard[b_i * bs: b_i * bs + n_b], dtype=torch.int64)
+                    packer.pack(row_local, index=idx, gen_ids=ids, gen_len=glen, first_logits=res.first_logits)
+                    dp.all_gather_rows(dist, row_local, out=row_all)
+                else:
+                    out = model.generate_output(batch)
+                t_prev_end = time.perf_counter()
+                if tracker is not None:
+                    tracker.update(t_prev_end - t1, n_b)
+                    done += len(out)
+                    st = dict(getattr(model, "last_stage_seconds", {}), total=t_prev_end - t1)
+                    stages.append({k: round(v * 1e3, 1) for k, v in st.items()})
+                if b_i == 0:
+                    prompt_tokens = [len(model.llama_tokenizer(p, add_special_tokens=False)["input_ids"]) for p in batch["prompt"][:4]]
+                last_b = b_i
+        barrier()
+        t_end = time.perf_counter()
+        overflow = loader.overflow_batches
+    finally:
+        loader.close()
     dt = t_end - t_start
     summ = tracker.get_summary()
+    gen_ms = [st["total"] for st in stages]
+    my_rate = done / dt
     mine = {"rank": rank, "utterances": done, "seconds": round(dt, 3),
-            "generate_output_ms": [st["total"] for st in stages], "between_batches_ms": gaps,
+            "generate_output_ms": gen_ms, "between_batches_ms": gaps,
             "host_ceiling_utt_per_s": round(host_rate, 1), "host_stage_ms_last_batch": stages[-1] if stages else None,
             "examples_per_second_tracker": summ.get("examples_per_second")}
-    note = ("ModelFactory -> SalmonProcessor/DataLoader -> generate_output; H2D of raw audio, prompt split + tokenisation "
-            "(stand-in sub-word tokenizer at ~3.9 chars per token: no Llama tokenizer files offline; prompt positions as listed, vs the "
-            "frozen 376), K1..K11 and batch_decode inside the timed region; first batches excluded as warm-up; utt_per_s counts every "
-            "timed batch (a batch whose ragged prompt lengths open a new decode-graph key pays its capture), utt_per_s_steady is "
-            "the median batch")
+    note = ("ModelFactory -> HF folder on local disk (" + f"{n_rows} distinct {secs:g} s clips stored as Arrow number lists, cycled) -> load_dataset -> "
+            "DatasetFactory / InferenceDataset -> SalmonProcessor -> ArenaBatchLoader -> generate_output; item pipeline, collation into "
+            "pinned shared slots, H2D of raw audio, prompt split + tokenisation (stand-in sub-word tokenizer at ~3.9 chars per token: no "
+            "Llama tokenizer files offline; prompt positions as listed, vs the frozen 376), K1..K11 and batch_decode inside the timed "
+            "region; first batches excluded as warm-up; host_ceiling = the same loader host-only over the same batches, after its first "
+            "wave; host_bound = ceiling < 1.5 x rate")
     if world == 1:
         del model
         if on_gpu:
             torch.cuda.empty_cache()
-        return {"utt_per_s": round(done / dt, 2), "examples_per_second_tracker": summ.get("examples_per_second"),
-                "batch_size": bs, "batches_timed": n_batches, "dataloader_workers": workers,
-                "host_ceiling_utt_per_s_per_rank": round(host_rate, 1),
+        steady = bs / (_median(gen_ms) * 1e-3) if gen_ms else None
+        return {"utt_per_s": round(my_rate, 2), "examples_per_second_tracker": summ.get("examples_per_second"),
+                "batch_size": bs, "batches_timed": len(gen_ms), "seconds_timed": round(dt, 1), "dataloader_workers": workers,
+                "loader_batches_in_flight": depth, "dataset_rows_on_disk": n_rows, "dataset_write_and_load_s": round(t_write, 1),
+                "host_ceiling_utt_per_s_per_rank": round(host_rate, 1), "host_ceiling_batches": len(stamps) - 1 - skip,
+                "host_bound": bool(host_rate < 1.5 * my_rate), "host_ceiling_over_rate": round(host_rate / my_rate, 2),
                 "host_stage_ms_last_batch": stages[-1] if stages else None,
-                "generate_output_ms_per_batch": mine["generate_output_ms"], "between_batches_ms": gaps,
-                "utt_per_s_steady": (round(bs / (_median(mine["generate_output_ms"]) * 1e-3), 2) if stages else None),
+                "generate_output_ms": {"min": min(gen_ms), "median": _median(gen_ms), "max": max(gen_ms)},
+                "between_batches_ms": {"min": min(gaps), "median": _median(gaps), "max": max(gaps)} if gaps else None,
+                "slot_overflow_batches": overflow,
+                "utt_per_s_steady": round(steady, 2) if steady else None,
                 "prompt_positions_first_rows": [t + N_AUDIO_TOK for t in prompt_tokens], "note": note}
     # ---- world > 1: MAX over ranks, every rank's figures to rank 0 (objects, outside the timed region) ----------------------
     tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -516,7 +585,7 @@ def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batche
     ok_idx = None
     if rank == 0:
         got = packer.unpack(row_all)
-        want = sorted(i for r in range(world) for i in dp.shard_indices(len(ds), r, world)[last_b * bs:(last_b + 1) * bs])
+        want = sorted(i for r in range(world) for i in dp.shard_indices(per_rank * world, r, world)[last_b * bs:(last_b + 1) * bs])
         ok_idx = sorted(got["index"].cpu().tolist()) == want
     del model
     if on_gpu:
@@ -525,25 +594,29 @@ def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batche
         return None
     gen = [x for m in everyone for x in m["generate_output_ms"]]
     gap = [x for m in everyone for x in m["between_batches_ms"]]
-    return {"utt_per_s": round(sum(m["utterances"] for m in everyone) / float(tt.item()), 2), "n_ranks": world,
-            "batch_size_per_rank": bs, "batches_timed_per_rank": n_batches, "seconds_max_over_ranks": round(float(tt.item()), 3),
+    node_rate = sum(m["utterances"] for m in everyone) / float(tt.item())
+    ceil_min = min(m["host_ceiling_utt_per_s"] for m in everyone)
+    return {"utt_per_s": round(node_rate, 2), "n_ranks": world,
+            "batch_size_per_rank": bs, "batches_timed_per_rank": len(gen_ms), "seconds_max_over_ranks": round(float(tt.item()), 3),
             "collective": f"all_gather_into_tensor per batch, {bs * packer.row_bytes} B per rank ({dist.get_backend()})",
             "last_batch_indices_ok": ok_idx,
             "generate_output_ms": {"min": min(gen), "median": _median(gen), "max": max(gen)},
             "between_batches_ms": {"min": min(gap), "median": _median(gap), "max": max(gap)} if gap else None,
-            "host_ceiling_utt_per_s_per_rank": {"min": min(m["host_ceiling_utt_per_s"] for m in everyone),
-                                                "max": max(m["host_ceiling_utt_per_s"] for m in everyone)},
+            "host_ceiling_utt_per_s_per_rank": {"min": ceil_min, "max": max(m["host_ceiling_utt_per_s"] for m in everyone)},
+            "host_bound": bool(ceil_min < 1.5 * node_rate / world), "host_ceiling_over_rate": round(ceil_min / (node_rate / world), 2),
+            "loader_batches_in_flight": depth, "dataset_rows_on_disk": n_rows,
             "host_cores": host_cores(), "host_threads_per_rank": torch.get_num_threads(), "dataloader_workers_per_rank": workers,
             "per_rank": everyone, "prompt_positions_first_rows": [t + N_AUDIO_TOK for t in prompt_tokens],
-            "note": note + "; world > 1: every rank runs its own DataLoader workers on its own shard (i = rank mod world), "
-                           "times are bracketed by barriers, utt_per_s = all ranks' utterances / MAX over ranks of the wall time"}
+            "note": note + "; world > 1: every rank runs its own workers on its own shard (i = rank mod world), all ranks' host-ceiling "
+                           "runs share the node's cores at the same time, times are bracketed by barriers, utt_per_s = all ranks' "
+                           "utterances / MAX over ranks of the wall time"}
 
 
 def quick_workload(wl: str, dev, batch: int = 64, steps: int = 3, warmup: int = 1, num_beams: int = 1):
     """One of the non-headline workloads of BASELINE.md §4, in THIS process (a process that has initialised the GPU must not
     start GPU children): build the seeded model, keep `warmup + steps` micro-batches resident, two untimed passes for the decode
     graph, then time `steps` passes.  Same step definition as the headline loop (encoders -> prefill -> 10 greedy tokens)."""
-    from icl_speech_text_llm_amd.runtime import synth
+    from icl_speech_text_llm_amd.runtime import binding as B, synth
     from icl_speech_text_llm_amd.runtime.config import QwenAudioCfg, SalmonnCfg
     wl_desc, wl_text, wl_naudio = WORKLOADS[wl]
     is_qwen = wl == "c4"
@@ -573,15 +646,24 @@ def quick_workload(wl: str, dev, batch: int = 64, steps: int = 3, warmup: int = 
     for s_ in range(max(warmup, 2)):          # eager pass + capture pass of the decode graph, before the clock
         step(min(s_, warmup + steps - 1))
     torch.cuda.synchronize()
+    profile = []
+    B.GEMM_PROFILE = profile
     t0 = time.perf_counter()
     for s_ in range(warmup, warmup + steps):
         toks = step(s_)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    B.GEMM_PROFILE = None
+    roof = workload_roofline(wl, batch * steps / dt, profile, dt) if num_beams == 1 else None
+    if roof is not None and batch == 1:      # one utterance per step streams every weight once per phase and per token: HBM-bound
+        roof["hbm"] = {"gb_per_utterance": 136.0, "peak_tb_s": 8.0, "frac": round(steps / dt * 136.0e9 / 8.0e12, 4),
+                       "hbm_floor_ms_per_utterance": 17.0, "note": "SURVEY.md §8d: (1.48 + 13.48 + 9 x 13.48) GB of weights per utterance at micro-batch 1"}
+    del profile
     out = {"workload": wl_desc + (f", beam search with {num_beams} beams" if num_beams > 1 else ""), "value": round(batch * steps / dt, 2), "unit": "utterances/s", "ms_per_step": round(dt / steps * 1e3, 1),
            "utterances_per_step": batch, "steps": steps,
            "prompt_positions": [t + wl_naudio * audio_tokens for t in wl_text] if len(wl_text) > 1 else wl_text[0] + wl_naudio * audio_tokens,
-           "new_tokens": int(toks.shape[1]), "workspace_gib": round(rt.ws.nbytes() / 2 ** 30, 1), "build_s": round(t_build, 1)}
+           "new_tokens": int(toks.shape[1]), "workspace_gib": round(rt.ws.nbytes() / 2 ** 30, 1), "build_s": round(t_build, 1),
+           "roofline": roof}
     del rt, wavs
     import gc
     gc.collect()
@@ -600,9 +682,8 @@ def main():
     # host threads and DataLoader workers per rank are bounded BEFORE anything touches the GPU: 8 ranks share the node's cores
     cores = host_cores()
     cores_per_rank = max(1, cores // max(world, 1))
-    if world > 1:
-        torch.set_num_threads(cores_per_rank)
-    plugin_workers = args.plugin_workers if world == 1 else max(1, min(args.plugin_workers, cores_per_rank - 1))
+    torch.set_num_threads(cores_per_rank)       # at N = 1 too: torch's default is the machine's core count, not the cgroup's share
+    plugin_workers = max(1, min(args.plugin_workers, cores_per_rank - 1))
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
@@ -738,17 +819,12 @@ def main():
     # ---- roofline of the dominant kernel, from live HIP-event timings -------------------------------
     roof = None
     if profile:
-        names = {1: "gemm_bf16_kernel<2,2,4,4> (128x128x64 tile)", 2: "gemm_bf16_kernel<2,2,2,2> (64x64x64 tile)",
-                 3: "gemm256_bf16_kernel (256x256x64 rolling LDS-DMA pipeline)"}
-        per_tile = {}
-        for (tile, sk, f, e0, e1, shape) in profile:
-            fl, tt, n = per_tile.get(tile, (0.0, 0.0, 0))
-            per_tile[tile] = (fl + f, tt + e0.elapsed_time(e1) * 1e-3, n + 1)
+        names = GEMM_KERNEL_NAMES
+        dom, per_tile = gemm_event_summary(profile, elapsed)
         all_t = sum(v[1] for v in per_tile.values())
-        dom = max(per_tile, key=lambda k: per_tile[k][1])          # dominant kernel = largest share of GPU time
         fl, tt, n = per_tile[dom]
         traffic, traffic_src = None, None
-        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:   # HBM-side bytes per launch of this kernel from the committed PMC passes of this same command (profiles/)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 key = {1: "gemm_bf16_kernel<2, 2, 4, 4>", 2: "gemm_bf16_kernel<2, 2, 2, 2>", 3: "gemm256_bf16_kernel"}[dom]
@@ -821,7 +897,8 @@ def main():
         log(f"through-plugin leg on all {world} ranks ({plugin_workers} DataLoader workers, {cores_per_rank} host threads per rank) ...")
         # no try / except here: a rank that fails must take the job down (non-zero exit under the launcher), not leave the
         # others waiting in a collective
-        plugin_block = through_plugin(args, dev, dist=dist, rank=rank, world=world, workers=plugin_workers)
+        plugin_block = through_plugin(args, dev, dist=dist, rank=rank, world=world, workers=plugin_workers,
+                                      gpu_rate=Bm * args.steps / elapsed)
         rt = None
     if rank == 0:
         n_utt = Bm * args.steps * world
@@ -855,7 +932,7 @@ def main():
         if world == 1 and want_plugin:
             log("through-plugin leg ...")
             try:
-                out["through_plugin"] = through_plugin(args, dev, workers=plugin_workers)
+                out["through_plugin"] = through_plugin(args, dev, workers=plugin_workers, gpu_rate=n_utt / elapsed)
             except Exception as e:       # a reported side number must never cost the headline line
                 out["through_plugin"] = {"error": f"{type(e).__name__}: {e}"}
             log(f"through-plugin: {out['through_plugin']}")
@@ -909,15 +986,19 @@ def main():
             import gc
             gc.collect()
             torch.cuda.empty_cache()
-            out["other_workloads"] = {"note": "BASELINE.json configs 4 and 5 (the 1-GPU half of 5) on this box, micro-batch 64, 3 timed steps "
-                                              "each after the graph warm-up, same step definition; run after the headline legs in this process; "
-                                              "c2_beams4 = the headline workload under num_beams=4 (64 prompts prefilled once, 256 beam "
-                                              "sequences decoded)"}
-            for wl in ("c4", "c5", "c2_beams4"):
+            out["other_workloads"] = {"note": "BASELINE.json configs 4 and 5 (the 1-GPU half of 5) on this box at micro-batch "
+                                              f"{args.other_batch} (prefilled 128 sequences at a time, decoded together), 3 timed steps each after "
+                                              "the graph warm-up, same step definition, each with its own roofline block (TFLOP per utterance "
+                                              "from SURVEY.md §8d; dominant GEMM kernel from live HIP events of the timed steps); run after the "
+                                              "headline legs in this process; c2_beams4 = the headline workload under num_beams=4 (64 prompts "
+                                              "prefilled once, 256 beam sequences decoded); batch1 = the reference CLI's own operating point "
+                                              "(--batch_size 1, inference/inference.py:62): one utterance per step, latency-bound"}
+            for wl in ("c4", "c5", "c2_beams4", "batch1"):
                 log(f"other workload {wl} ...")
                 try:
                     out["other_workloads"][wl] = (quick_workload("c2", dev, num_beams=4) if wl == "c2_beams4" else
-                                                  quick_workload(wl, dev))
+                                                  quick_workload("c2", dev, batch=1, steps=20, warmup=2) if wl == "batch1" else
+                                                  quick_workload(wl, dev, batch=args.other_batch))
                 except Exception as e:      # a reported side number must never cost the headline line
                     out["other_workloads"][wl] = {"error": f"{type(e).__name__}: {e}"}
                     torch.cuda.empty_cache()

@@ -3,7 +3,8 @@
 Mirrors the reference's ``SalmonProcessor`` (data/model_processors.py:476-874) for the classification
 tasks: ``format_prompt`` reproduces ``_format_default_prompt`` (:742-776) character for character (the
 prompt text fixes the token count S), ``process_inputs`` / ``collate_batch`` emit the batch dict of
-SURVEY.md §8(a-0) (:616-681, :786-874).
+SURVEY.md §8(a-0) (:616-681, :786-874) — with the boolean padding masks derived on demand from the lengths
+(``CollatedBatch``) and the waveforms collated once, straight into the worker's shared-memory batch tensor.
 
 MI355X-first difference: the log-mel (K1) moved onto the GPU, so by default the processor ships
 ``raw_wav`` (as float32 — the reference's ``torch.tensor(audio)`` keeps numpy float64) and NO
@@ -18,9 +19,86 @@ from typing import Any, Dict, List, Optional
 
 import numpy as np
 import torch
-from torch.nn.utils.rnn import pad_sequence
 
 from .task_configs import DatasetType
+
+
+_ARENA = None         # the collate destination of the current process while utils/batch_loader.collate_into(...) is active
+
+
+def _batch_tensor(shape, dtype) -> torch.Tensor:
+    """An uninitialised batch tensor; inside a DataLoader worker it is allocated in shared memory straight away (what
+    ``default_collate`` does for stacked tensors), so handing the batch to the main process is a file-descriptor pass, not
+    another 0.5 GB copy into shared memory."""
+    if _ARENA is not None:                # utils/batch_loader.py: a preallocated, pinned, shared-memory slot of the batch loader
+        t = _ARENA.take(shape, dtype)
+        if t is not None:
+            return t
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if torch.utils.data.get_worker_info() is not None and n > 0:
+        proto = torch.empty(0, dtype=dtype)
+        return proto.new(proto._typed_storage()._new_shared(n)).resize_(*[int(d) for d in shape])
+    return torch.empty(*[int(d) for d in shape], dtype=dtype)
+
+
+def _pad_rows(rows: List[torch.Tensor], width: Optional[int] = None) -> torch.Tensor:
+    """``pad_sequence(rows, batch_first=True)`` written once: every waveform is copied exactly once, into its row of the
+    (shared-memory) batch tensor, and only the padding tail of a row is zero-filled."""
+    width = max(int(r.numel()) for r in rows) if width is None else width
+    out = _batch_tensor((len(rows), width), rows[0].dtype)
+    for i, r in enumerate(rows):
+        n = int(r.numel())
+        out[i, :n] = r.reshape(-1)
+        if n < width:
+            out[i, n:] = 0
+    return out
+
+
+class CollatedBatch(dict):
+    """The batch dict of SURVEY.md §8(a-0) with its boolean padding masks derived ON DEMAND.
+
+    The reference's collate materialises ``padding_mask`` bool [B, L] (``data/model_processors.py:802``) and its model turns
+    it straight back into lengths.  At 256 x 480 000 that is 123 MB per batch through worker shared memory, the pin thread
+    and PCIe for a tensor nobody needs: the lengths travel as ``wav_lengths`` [B].  The masks are therefore not stored;
+    ``batch["padding_mask"]`` (``"padding_mask" in batch``, ``batch.get("padding_mask")``) builds the reference's tensor from
+    the lengths the first time a caller asks, on the device the waveforms live on."""
+
+    _MASKS = {   # mask key -> (waveform key, lengths key)
+        "padding_mask": ("raw_wav", "wav_lengths"),
+        "example_padding_masks": ("example_wavs", "example_wav_lengths"),
+        "question_padding_mask": ("question_raw_wav", "question_wav_lengths"),
+        "document_padding_mask": ("document_raw_wav", "document_wav_lengths"),
+        "example_question_padding_masks": ("example_question_wavs", "example_question_wav_lengths"),
+        "example_document_padding_masks": ("example_document_wavs", "example_document_wav_lengths"),
+    }
+
+    def _derivable(self, key) -> bool:
+        src = self._MASKS.get(key)
+        return src is not None and dict.__contains__(self, src[0]) and dict.__contains__(self, src[1])
+
+    def __contains__(self, key) -> bool:
+        return dict.__contains__(self, key) or self._derivable(key)
+
+    def __missing__(self, key):
+        if not self._derivable(key):
+            raise KeyError(key)
+        wav_key, len_key = self._MASKS[key]
+        wavs, lens = dict.__getitem__(self, wav_key), dict.__getitem__(self, len_key)
+        lens = lens.to(wavs.device)
+        mask = torch.arange(wavs.shape[-1], device=wavs.device).expand(wavs.shape) >= lens.unsqueeze(-1)
+        self[key] = mask
+        return mask
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __reduce__(self):      # pickled (worker -> main process) and copied (pin_memory, device_prefetch) as this class
+        return (type(self), (dict(self),))
+
+    def copy(self):
+        return type(self)(self)
 
 
 def _is_sqa(dataset_type) -> bool:
@@ -80,7 +158,10 @@ class SalmonProcessor:
 
     # ---- one item ----------------------------------------------------------------------------------
     def _audio(self, audio) -> Dict[str, Any]:
-        wav = torch.as_tensor(np.asarray(audio), dtype=torch.float32).reshape(-1)
+        arr = np.asarray(audio)
+        if arr.dtype == np.float32 and not arr.flags.writeable:      # a view of a memory-mapped Arrow buffer: torch wants its own
+            arr = arr.copy()
+        wav = torch.as_tensor(arr, dtype=torch.float32).reshape(-1)
         out = {"raw_wav": wav, "wav_length": int(wav.numel()), "spectrogram": None}
         if self.compute_spectrogram:
             out["spectrogram"] = self.processor(np.asarray(audio), sampling_rate=16000, return_tensors="pt").input_features.squeeze(0)
@@ -124,41 +205,35 @@ class SalmonProcessor:
     def collate_batch(self, items: List[Dict[str, Any]]) -> Dict[str, Any]:
         if _is_sqa(items[0].get("dataset_type")):
             return self._collate_sqa_batch(items)
-        batch: Dict[str, Any] = {
+        batch: Dict[str, Any] = CollatedBatch({
             "input_ids": torch.stack([it["input_ids"] for it in items]),
             "attention_mask": torch.stack([it["attention_mask"] for it in items]),
-        }
+        })
         if all(it.get("raw_wav") is not None for it in items):
-            lens = torch.tensor([it["wav_length"] for it in items])
-            wavs = pad_sequence([it["raw_wav"] for it in items], batch_first=True, padding_value=0.0)
-            batch["wav_lengths"] = lens
-            batch["raw_wav"] = wavs
-            batch["padding_mask"] = torch.arange(wavs.size(1)).unsqueeze(0) >= lens.unsqueeze(1)
+            batch["wav_lengths"] = torch.tensor([it["wav_length"] for it in items])
+            batch["raw_wav"] = _pad_rows([it["raw_wav"] for it in items])       # "padding_mask": derived on demand (CollatedBatch)
             if all(it.get("spectrogram") is not None for it in items):
                 batch["spectrogram"] = torch.stack([it["spectrogram"] for it in items])
         max_examples = max(it["num_examples"] for it in items)
         if max_examples > 0 and any(it.get("examples_speech") for it in items):
             max_len = max(ex["wav_length"] for it in items for ex in it["examples_speech"][:it["num_examples"]])
             have_spec = all(ex["spectrogram"] is not None for it in items for ex in it["examples_speech"])
-            ex_wavs, ex_masks, ex_lens, ex_specs = [], [], [], []
-            for it in items:
-                w = torch.zeros(max_examples, max_len)
-                m = torch.ones(max_examples, max_len, dtype=torch.bool)
-                l = torch.zeros(max_examples, dtype=torch.long)
-                s = torch.zeros(max_examples, 80, 3000)
-                for e, ex in enumerate(it["examples_speech"][:it["num_examples"]]):
+            w = _batch_tensor((len(items), max_examples, max_len), torch.float32)
+            l = torch.zeros(len(items), max_examples, dtype=torch.long)
+            sp = torch.zeros(len(items), max_examples, 80, 3000) if have_spec else None
+            for b, it in enumerate(items):
+                row = it["examples_speech"][:it["num_examples"]]
+                for e, ex in enumerate(row):
                     n = ex["wav_length"]
-                    w[e, :n] = ex["raw_wav"]
-                    m[e, :n] = False
-                    l[e] = n
+                    w[b, e, :n] = ex["raw_wav"]
+                    w[b, e, n:] = 0
+                    l[b, e] = n
                     if have_spec:
-                        s[e] = ex["spectrogram"]
-                ex_wavs.append(w); ex_masks.append(m); ex_lens.append(l); ex_specs.append(s)
-            batch["example_wavs"] = torch.stack(ex_wavs)
-            batch["example_padding_masks"] = torch.stack(ex_masks)
-            batch["example_wav_lengths"] = torch.stack(ex_lens)
+                        sp[b, e] = ex["spectrogram"]
+                w[b, len(row):] = 0
+            batch["example_wavs"], batch["example_wav_lengths"] = w, l           # "example_padding_masks": on demand
             if have_spec:
-                batch["example_spectrograms"] = torch.stack(ex_specs)
+                batch["example_spectrograms"] = sp
         batch["num_examples"] = torch.tensor([it["num_examples"] for it in items])
         for key in ("prompt", "completion", "text", "dataset_type"):
             if key in items[0]:
@@ -167,14 +242,12 @@ class SalmonProcessor:
 
 
     def _collate_sqa_batch(self, items: List[Dict[str, Any]]) -> Dict[str, Any]:
-        batch: Dict[str, Any] = {"input_ids": torch.stack([it["input_ids"] for it in items]),
-                                 "attention_mask": torch.stack([it["attention_mask"] for it in items])}
+        batch: Dict[str, Any] = CollatedBatch({"input_ids": torch.stack([it["input_ids"] for it in items]),
+                                               "attention_mask": torch.stack([it["attention_mask"] for it in items])})
         if all(it.get("question_raw_wav") is not None and it.get("document_raw_wav") is not None for it in items):
             for side in ("question", "document"):
-                lens = torch.tensor([it[f"{side}_wav_length"] for it in items])
-                wavs = pad_sequence([it[f"{side}_raw_wav"] for it in items], batch_first=True, padding_value=0.0)
-                batch[f"{side}_wav_lengths"], batch[f"{side}_raw_wav"] = lens, wavs
-                batch[f"{side}_padding_mask"] = torch.arange(wavs.size(1)).unsqueeze(0) >= lens.unsqueeze(1)
+                batch[f"{side}_wav_lengths"] = torch.tensor([it[f"{side}_wav_length"] for it in items])
+                batch[f"{side}_raw_wav"] = _pad_rows([it[f"{side}_raw_wav"] for it in items])   # masks: on demand
                 if all(it.get(f"{side}_spectrogram") is not None for it in items):
                     batch[f"{side}_spectrogram"] = torch.stack([it[f"{side}_spectrogram"] for it in items])
         max_examples = max(it["num_examples"] for it in items)
@@ -185,17 +258,15 @@ class SalmonProcessor:
                 max_len = max(e["wav_length"] for row in exs for e in row)
                 have_spec = all(e["spectrogram"] is not None for row in exs for e in row)
                 w = torch.zeros(len(items), max_examples, max_len)
-                m = torch.ones(len(items), max_examples, max_len, dtype=torch.bool)
                 l = torch.zeros(len(items), max_examples, dtype=torch.long)
                 sp = torch.zeros(len(items), max_examples, 80, 3000) if have_spec else None
                 for b, row in enumerate(exs):
                     for e, ex in enumerate(row):
                         n = ex["wav_length"]
-                        w[b, e, :n], m[b, e, :n], l[b, e] = ex["raw_wav"], False, n
+                        w[b, e, :n], l[b, e] = ex["raw_wav"], n
                         if have_spec:
                             sp[b, e] = ex["spectrogram"]
-                batch[f"example_{side}_wavs"], batch[f"example_{side}_padding_masks"] = w, m
-                batch[f"example_{side}_wav_lengths"] = l
+                batch[f"example_{side}_wavs"], batch[f"example_{side}_wav_lengths"] = w, l
                 if have_spec:
                     batch[f"example_{side}_spectrograms"] = sp
         batch["num_examples"] = torch.tensor([it["num_examples"] for it in items])

@@ -16,6 +16,7 @@ log-mel (the reference's ``torch.tensor(audio)`` keeps float64 — SURVEY.md §8
 from __future__ import annotations
 
 from ..utils.audio_io import decode_audio
+from .arrow_audio import FastAudioRows
 
 import logging
 import random
@@ -68,6 +69,10 @@ class BaseMultiTaskDataset(Dataset):
         self.is_swap_dataset = is_swap_type(self.dataset_type)
         if not self.is_swap_dataset:
             self.current_config = self.config
+        # number-list audio columns are read zero-copy from the Arrow table (data/arrow_audio.py): dataset[idx] would box a 30 s
+        # clip into 480 000 Python floats (~120 ms per row) only for the next line to turn them back into an array
+        self._fast_rows = FastAudioRows.wrap(dataset)
+        self._fast_lookup = None
         self.audio_lookup = None
         self.audio_index_map = None
         path = self.config.get_audio_lookup_path(self.split)
@@ -76,6 +81,7 @@ class BaseMultiTaskDataset(Dataset):
                 from datasets import load_from_disk
             t0 = time.time()
             self.audio_lookup = load_from_disk(path)
+            self._fast_lookup = FastAudioRows.wrap(self.audio_lookup)
             if self.dataset_type.name not in _LOOKUP_SAMPLED:
                 self.audio_index_map = {str(v): i for i, v in enumerate(self.audio_lookup["index"])}
             logger.info("Initialized audio lookup for %s in %.3fs", self.dataset_type, time.time() - t0)
@@ -126,6 +132,9 @@ class BaseMultiTaskDataset(Dataset):
             return random.sample(range(total), min(k, total)) if k > 0 else []
         return random.sample(range(total), min(self.num_examples, total))
 
+    def _lookup_row(self, i: int):
+        return self._fast_lookup.row(i) if self._fast_lookup is not None else self.audio_lookup[i]
+
     def _get_audio_by_index(self, index_str):
         if not index_str:
             return None
@@ -137,7 +146,7 @@ class BaseMultiTaskDataset(Dataset):
             if i is None:
                 logger.warning("No matching audio found for index %s", index_str)
                 return None
-            return self.audio_lookup[i]["audio"]
+            return self._lookup_row(i)["audio"]
         except Exception as e:
             logger.error("Error loading audio for index %s: %s", index_str, e)
             return None
@@ -168,7 +177,7 @@ class BaseMultiTaskDataset(Dataset):
     def __getitem__(self, idx):
         if self.is_swap_dataset:
             self.current_config = get_swap_config(self.dataset_type, self.randomize_swap)
-        item = self.dataset[idx]
+        item = self._fast_rows.row(idx) if self._fast_rows is not None else self.dataset[idx]
         if self.dataset_type.name == "SQA":
             return self._process_sqa_item(item, idx)
         return self._process_default_item(item, idx)
@@ -179,7 +188,7 @@ class BaseMultiTaskDataset(Dataset):
         examples_audio: Optional[List[np.ndarray]] = []
         if self.dataset_type.name in _LOOKUP_SAMPLED and self.audio_lookup is not None and self.num_examples > 0:
             for i in self._sample_lookup_indices():
-                ex = self.audio_lookup[i]
+                ex = self._lookup_row(i)
                 examples.append({"text": ex[cfg.text_key],
                                  "label": self._format_label(ex[cfg.completion_key], is_example=False,
                                                              current_mapping=cfg.label_mapping, text=ex[cfg.text_key])})
@@ -214,7 +223,7 @@ class BaseMultiTaskDataset(Dataset):
         if self.audio_lookup is not None and self.num_examples > 0:
             examples_audio = []
             for i in self._sample_lookup_indices():
-                ex = self.audio_lookup[i]
+                ex = self._lookup_row(i)
                 examples.append({"question": ex[q_key], "document": ex[cfg.text_key],
                                  "completion": self._format_label(ex[cfg.completion_key], is_example=False,
                                                                   current_mapping=cfg.label_mapping)})

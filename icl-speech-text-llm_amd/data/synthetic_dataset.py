@@ -185,3 +185,50 @@ def write_synthetic_hf_datasets(root: str, dataset_types: Sequence[DatasetType],
             for path, table in ((cfg.get_path(sp), rows), (cfg.get_audio_lookup_path(sp), lookup_rows)):
                 if path and not os.path.exists(path):
                     HFDataset.from_list(table).save_to_disk(path)
+
+
+def write_voxceleb_folder_arrow(root: str, n_items: int, seconds: float = 30.0, seed: int = 1234, n_fewshot: int = 5,
+                                value_type: str = "float32") -> str:
+    """A VOXCELEB test folder (+ its audio-lookup folder) of ``n_items`` rows with ``seconds``-long clips, written through Arrow
+    arrays instead of Python lists (``write_synthetic_hf_datasets`` spends ~0.2 s per 30 s clip boxing floats: fine for six-row
+    test folders, not for the few hundred clips a throughput run cycles through).  Same columns as the reference's item
+    pipeline reads (data/multi_task_dataset.py:231-462): ``normalized_text``, ``sentiment``, ``audio{array, sampling_rate}``,
+    ``few_shot_examples[{text, label, index}]``; audio = N(0, 0.1^2) clipped to [-1, 1], ``default_rng(seed + i)``
+    (SURVEY.md §8d).  Returns the dataset folder."""
+    import os
+    import pyarrow as pa
+    import datasets
+    from datasets import Dataset as HFDataset
+    datasets.disable_progress_bars()
+    from .task_configs import DatasetSplit, set_dataset_root
+    set_dataset_root(root)
+    cfg = get_dataset_config(DatasetType.VOXCELEB)
+    path, lookup_path = cfg.get_path(DatasetSplit.TEST), cfg.get_audio_lookup_path(DatasetSplit.TEST)
+    if os.path.exists(path) and (not lookup_path or os.path.exists(lookup_path)):
+        return path
+    labels = list(cfg.label_mapping) if cfg.label_mapping else list(cfg.valid_labels)
+    rng = np.random.default_rng(seed)
+    n_lookup = max(8, n_fewshot + 3)
+    lookup = [{"index": str(1000 + i), cfg.text_key: _sentence(rng, 75), cfg.completion_key: str(rng.choice(labels))} for i in range(n_lookup)]
+
+    def audio_column(n_rows, n_samples, first_seed):
+        vals = np.empty(n_rows * n_samples, dtype=value_type)
+        for i in range(n_rows):
+            vals[i * n_samples:(i + 1) * n_samples] = np.clip(np.random.default_rng(first_seed + i).normal(0.0, 0.1, n_samples), -1.0, 1.0)
+        # 64-bit offsets: 512 clips of 30 s are 2.5e8 values, a few thousand would pass 2^31
+        arr = pa.LargeListArray.from_arrays(pa.array(np.arange(n_rows + 1, dtype=np.int64) * n_samples), pa.array(vals))
+        return pa.StructArray.from_arrays([arr, pa.array(np.full(n_rows, 16000, dtype=np.int64))], ["array", "sampling_rate"])
+
+    n = int(round(seconds * 16000))
+    texts = [_sentence(rng, 75) for _ in range(n_items)]
+    shots = [[{"text": lookup[int(j)][cfg.text_key], "label": lookup[int(j)][cfg.completion_key], "index": lookup[int(j)]["index"]}
+              for j in rng.choice(n_lookup, size=min(n_fewshot, n_lookup), replace=False)] for _ in range(n_items)]
+    table = pa.table({cfg.text_key: pa.array(texts), cfg.completion_key: pa.array([str(rng.choice(labels)) for _ in range(n_items)]),
+                      "audio": audio_column(n_items, n, seed), "few_shot_examples": pa.array(shots)})
+    HFDataset(table).save_to_disk(path)
+    if lookup_path:
+        lk = pa.table({"index": pa.array([r["index"] for r in lookup]), cfg.text_key: pa.array([r[cfg.text_key] for r in lookup]),
+                       cfg.completion_key: pa.array([r[cfg.completion_key] for r in lookup]),
+                       "audio": audio_column(n_lookup, 16000, seed + 10 ** 6)})
+        HFDataset(lk).save_to_disk(lookup_path)
+    return path

@@ -10,11 +10,17 @@ Differences, all additive:
     ``SyntheticICLDataset`` (same item schema and prompt templates, 30 s clips);
   * data-parallel inference: launched under ``torchrun`` (one process per GPU) the utterances are sharded
     ``i ≡ rank (mod world)`` and rank 0 gathers every rank's results before scoring (the reference's inference is
-    single-process); ``--batch_size`` defaults to 64, not the reference's 1 (its collate stacks un-padded prompts, :448-450): ragged prompts
-    batch fine here and a row's speech embeddings, prefill and first-step logits do not depend on its batch (tested bit for bit;
-    later tokens within the decode kernels' tolerance), so the default is a throughput choice
-    — 64 utterances keep the workspace under ~45 GiB for every supported model; ``--batch_size 256`` is the headline setting
-    (140 utterances/s on one MI355X, ~140 GiB of HBM), ``--batch_size 1`` reproduces the reference's loop shape at ~16/s.
+    single-process, SURVEY.md §0.5);
+  * ``--batch_size`` defaults to AUTO, not the reference's 1 (its collate stacks un-padded prompts, :448-450, so 1 is all it can
+    run): ragged prompts batch fine here and a row's speech embeddings, prefill and first-step logits do not depend on its
+    batch (tested bit for bit; later tokens within the decode kernels' tolerance), so the default is a throughput choice made
+    per model from the HBM that is free — 256 utterances for SALMONN-7B on an MI355X (the headline setting: ~145 utterances/s,
+    ~140 GiB of HBM), 128 for SALMONN-13B, 64 for Qwen2-Audio (`auto_batch_size`); ``--batch_size 1`` reproduces the
+    reference's loop shape;
+  * ``--num_workers`` defaults to the cores this process may use divided by the ranks on the node, minus one for the main
+    thread, at most 8 (the reference: 4); batches come from ``utils/batch_loader.ArenaBatchLoader`` — workers collate straight
+    into preallocated pinned shared-memory slots and the H2D copy of batch i+1 runs under batch i's kernels — instead of
+    ``DataLoader`` + ``pin_memory`` (same batches, same order: tests/test_host_pipeline.py).
 The host loop is pinned to the reference's own ``run_inference`` by tests/golden/cli_loop.json (records, order, failing batch,
 ``--max_samples`` limiting whole batches, ``--debug_samples``, output files).
 """
@@ -31,14 +37,15 @@ import traceback
 from typing import Any, Dict, List
 
 import torch
-from torch.utils.data import DataLoader, Subset
+from torch.utils.data import Subset
 
 from ..config.inference_config import get_inference_config
 from ..data.model_processors import get_processor
 from ..data.synthetic_dataset import SyntheticICLDataset
 from ..data.dataset_factory import DatasetFactory
 from ..data.task_configs import DatasetType, parse_dataset_types, set_dataset_root
-from ..utils.data_utils import device_prefetch, load_dataset
+from ..utils.batch_loader import ArenaBatchLoader
+from ..utils.data_utils import load_dataset
 from ..models.model_factory import ModelFactory, load_finetuned_checkpoint
 from ..utils.evaluation_utils import clean_prediction, evaluate_predictions
 from ..utils.performance_utils import PerformanceTracker
@@ -63,10 +70,12 @@ def parse_args(argv=None):
     p.add_argument("--input_mode", type=str, default="speech_only", choices=["speech_only", "text_only", "speech_and_text"])
     p.add_argument("--fewshot_mode", type=str, default="text", choices=["text", "speech"])
     p.add_argument("--model_type", type=str, default="salmonn")
-    p.add_argument("--batch_size", type=int, default=64,
-                   help="utterances per generate call (reference default 1; results are batch-invariant; 256 = headline throughput)")
+    p.add_argument("--batch_size", type=int, default=None,
+                   help="utterances per generate call (default: auto from the model and the free HBM — 256 for SALMONN-7B on an "
+                        "MI355X; reference default 1; results are batch-invariant)")
     p.add_argument("--num_examples", type=int, default=5)
-    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--num_workers", type=int, default=None,
+                   help="item-pipeline worker processes of this rank (default: usable cores / ranks on the node - 1, at most 8; reference: 4)")
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--max_samples", type=int, default=None)
     p.add_argument("--save_per_dataset", action="store_true")
@@ -95,6 +104,48 @@ def parse_args(argv=None):
 def _dist_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     return int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def usable_cores() -> int:
+    """Cores this process may run on: scheduler affinity, capped by a cgroup CPU quota when one is set."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def default_num_workers(world: int) -> int:
+    """Item-pipeline workers per rank: the ranks of a node share its cores (8 ranks x 4 workers on 16 cores would oversubscribe
+    them 2x), one core per rank stays with the main thread that drives the GPU."""
+    return max(1, min(8, usable_cores() // max(1, world) - 1))
+
+
+def auto_batch_size(model, device) -> int:
+    """Utterances per generate call when ``--batch_size`` is not given: the widest batch of the model family that leaves the
+    workspace (activations + K/V, measured per utterance at the BASELINE prompt lengths: 0.37 GiB SALMONN-7B, 0.68 GiB
+    SALMONN-13B, 0.84 GiB Qwen2-Audio) plus two copies of the decoder weights inside 70 % of the HBM that is free now."""
+    dev = torch.device(device)
+    cfg = getattr(model, "cfg", None)
+    lm = getattr(cfg, "llama", None) or getattr(cfg, "llm", None)
+    if dev.type != "cuda" or lm is None:
+        return 8
+    is_qwen = hasattr(cfg, "audio_token_id")
+    per_utt = 0.84 if is_qwen else 0.68 if lm.hidden > 4096 else 0.37
+    weights = 2 * 12 * lm.hidden * lm.hidden * lm.n_layers * 2 / 2 ** 30 * 1.1
+    free = torch.cuda.mem_get_info(dev)[0] / 2 ** 30 + torch.cuda.memory_reserved(dev) / 2 ** 30 - torch.cuda.memory_allocated(dev) / 2 ** 30
+    bs = 64 if is_qwen else 256
+    while bs > 1 and per_utt * bs + weights > 0.7 * free:
+        bs //= 2
+    return bs
 
 
 def _tokenizer_of(model):
@@ -168,6 +219,11 @@ def run_inference(args) -> Dict[str, Any]:
         else:
             logger.info("No checkpoint path provided, using base model without loading weights")
         model.to(args.device)
+        if args.num_workers is None:
+            args.num_workers = default_num_workers(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        if args.batch_size is None:
+            args.batch_size = auto_batch_size(model, args.device)
+            logger.info("--batch_size not given: %d utterances per generate call (auto)", args.batch_size)
         if isinstance(getattr(model, "generation_config", None), dict):      # Qwen2-Audio: knobs live in the model's generation config
             model.generation_config["max_new_tokens"] = args.max_new_tokens       # (--max_new_tokens is this CLI's addition; 10 = reference)
         if args.model_type == "salmonn":
@@ -206,9 +262,8 @@ def run_inference(args) -> Dict[str, Any]:
         if args.max_samples is not None:
             total = min(total, -(-args.max_samples // args.batch_size) * args.batch_size)
         indices = shard_indices(total, rank, world)   # i ≡ rank (mod world), no padding duplicates
-        loader = DataLoader(Subset(dataset, indices), batch_size=args.batch_size, shuffle=False,
-                            num_workers=args.num_workers, pin_memory=args.pin_memory and torch.cuda.is_available(),
-                            collate_fn=processor.collate_batch)
+        loader = ArenaBatchLoader(Subset(dataset, indices), args.batch_size, processor.collate_batch, num_workers=args.num_workers,
+                                  device=args.device, pin_memory=args.pin_memory and torch.cuda.is_available())
         model.eval()
         label_names, label_ids = _label_token_ids(model, dataset_types)
         pad_id = _pad_token_id(model)
@@ -218,7 +273,7 @@ def run_inference(args) -> Dict[str, Any]:
         failed_batches = failed_rows = 0
         fatal = None
         with torch.no_grad():
-            for batch_idx, batch in enumerate(device_prefetch(loader, args.device)):      # batch i+1's H2D under batch i's kernels
+            for batch_idx, batch in enumerate(loader):      # batch i+1 is collated and copied to the device under batch i's kernels
                 n_b = len(batch["prompt"])
                 b_idx = indices[batch_idx * args.batch_size: batch_idx * args.batch_size + n_b]
                 try:
@@ -317,6 +372,8 @@ def run_inference(args) -> Dict[str, Any]:
         logger.debug(traceback.format_exc())
         raise RuntimeError(f"Inference failed: {e}") from e
     finally:
+        if "loader" in locals():
+            loader.close()
         if dist is not None and dist.is_initialized():
             dist.destroy_process_group()
 

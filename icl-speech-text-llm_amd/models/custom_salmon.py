@@ -338,10 +338,15 @@ class CustomSALMONN(BaseModel):
         return self.salmonn.encode_speech(spectrogram=spectrogram, raw_wav=raw_wav, audio_padding_mask=audio_padding_mask)
 
     @staticmethod
-    def _lengths(wavs: torch.Tensor, lens, mask) -> List[int]:
+    def _lengths(wavs: torch.Tensor, samples: Dict[str, Any], len_key: str, mask_key: str) -> List[int]:
+        """Valid samples per waveform: the batch's length vector when it carries one (this build's collate always does), else
+        the reference's boolean padding mask (:407-441 read only the mask), else the full width.  The mask is looked up LAST:
+        a ``CollatedBatch`` derives it on demand, and asking for it would build a [B, L] tensor only to count it again."""
+        lens = samples.get(len_key)
         if lens is not None:
             flat = lens.reshape(-1).tolist() if isinstance(lens, torch.Tensor) else list(lens)
             return [int(x) for x in flat]
+        mask = samples.get(mask_key)
         if mask is not None:
             return (~mask.bool()).sum(dim=-1).reshape(-1).tolist()
         return [wavs.shape[-1]] * int(wavs.numel() // wavs.shape[-1])
@@ -364,21 +369,25 @@ class CustomSALMONN(BaseModel):
         if use_wav:
             rows, valid, padded = [], [], []
             if has_main:
-                lens = self._lengths(main_wav, samples.get("wav_lengths"), samples.get("padding_mask"))
+                lens = self._lengths(main_wav, samples, "wav_lengths", "padding_mask")
                 for b in range(B):
                     rows.append(main_wav[b]); valid.append(lens[b]); padded.append(main_wav.shape[1]); owners.append((b, -1))
             if has_ex:
                 E = ex_wav.shape[1]
-                elens = self._lengths(ex_wav, samples.get("example_wav_lengths"), samples.get("example_padding_masks"))
+                elens = self._lengths(ex_wav, samples, "example_wav_lengths", "example_padding_masks")
                 nex = samples.get("num_examples")
                 for b in range(ex_wav.shape[0]):
                     k = int(nex[b]) if nex is not None else E
                     for e in range(min(E, k)):
                         rows.append(ex_wav[b, e]); valid.append(elens[b * E + e]); padded.append(ex_wav.shape[2]); owners.append((b, e))
-            L = max(r.shape[0] for r in rows)
-            wav = torch.zeros(len(rows), L, dtype=torch.float32, device=self.device)
-            for i, r in enumerate(rows):
-                wav[i, :r.shape[0]] = r.to(device=self.device, dtype=torch.float32)
+            if (not has_ex and main_wav.dtype == torch.float32 and main_wav.is_cuda and main_wav.is_contiguous()
+                    and main_wav.device == PackedTreeModule._indexed(self.device)):
+                wav = main_wav          # the collated device batch IS the kernel's operand: no per-row gather copies
+            else:
+                L = max(r.shape[0] for r in rows)
+                wav = torch.zeros(len(rows), L, dtype=torch.float32, device=self.device)
+                for i, r in enumerate(rows):
+                    wav[i, :r.shape[0]] = r.to(device=self.device, dtype=torch.float32)
             emb = rt.encode_speech(wav, valid, padded_lens=padded)
         else:   # caller supplied spectrograms only (no BEATs stream possible)
             specs = []
@@ -423,7 +432,7 @@ class CustomSALMONN(BaseModel):
             B = q_wav.shape[0]
             for side, wav in (("q", q_wav), ("d", d_wav)):
                 name = "question" if side == "q" else "document"
-                lens = self._lengths(wav, samples.get(f"{name}_wav_lengths"), samples.get(f"{name}_padding_mask"))
+                lens = self._lengths(wav, samples, f"{name}_wav_lengths", f"{name}_padding_mask")
                 for b in range(B):
                     rows.append(wav[b]); valid.append(lens[b]); padded.append(wav.shape[1]); owners.append((b, side, -1))
         if has_ex:
@@ -431,7 +440,7 @@ class CustomSALMONN(BaseModel):
             nex = samples.get("num_examples")
             for side, wav in (("q", eq_wav), ("d", ed_wav)):
                 name = "question" if side == "q" else "document"
-                lens = self._lengths(wav, samples.get(f"example_{name}_wav_lengths"), samples.get(f"example_{name}_padding_masks"))
+                lens = self._lengths(wav, samples, f"example_{name}_wav_lengths", f"example_{name}_padding_masks")
                 for b in range(B):
                     for e in range(min(E, int(nex[b]) if nex is not None else E)):
                         rows.append(wav[b, e]); valid.append(lens[b * E + e]); padded.append(wav.shape[2]); owners.append((b, side, e))

@@ -8,7 +8,8 @@ every form such a cell can take on disk or in memory, so the item pipeline also 
 * ``{"bytes": ..., "path": ...}``            — an ``Audio(decode=False)`` cell: RIFF/WAVE PCM (8/16/24/32-bit) or IEEE float
   (32/64-bit) is parsed here with the standard library; other containers (FLAC, MP3, OGG) need a decoder backend and raise
   a clear error;
-* a bare array / list.
+* a bare array / list;
+* a ``LazyAudio`` handle (data/arrow_audio.py): a cell of a number-list column that is read straight from the Arrow buffers.
 
 Multi-channel audio is averaged to mono, other sampling rates are resampled to 16 kHz (polyphase, scipy) — both additive:
 the reference would feed such audio unchanged.
@@ -70,6 +71,8 @@ def decode_audio(cell: Any, target_sr: int = TARGET_SR) -> Optional[np.ndarray]:
     """One audio cell (see module docstring) -> float32 [n] at ``target_sr``, or None for an empty cell."""
     if cell is None:
         return None
+    if not isinstance(cell, (dict, np.ndarray, list, tuple)) and callable(getattr(cell, "load", None)):
+        return cell.load()                           # data/arrow_audio.LazyAudio: a cell of a number-list column, read zero-copy
     sr = target_sr
     if isinstance(cell, dict):
         if cell.get("array") is not None:

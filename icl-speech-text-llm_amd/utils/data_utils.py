@@ -46,6 +46,7 @@ def device_prefetch(loader, device):
     when the DataLoader pins its batches) while the caller's kernels for batch i run, instead of a blocking ``.to(device)``
     between two batches (246 MB of raw audio per 128 utterances).  Yields batch dicts whose tensors live on ``device``; the
     consumer's current stream waits for the copy of the batch it receives.  On a CPU device it is a plain pass-through."""
+    import copy
     import torch
     dev = torch.device(device)
     if dev.type != "cuda":
@@ -59,8 +60,9 @@ def device_prefetch(loader, device):
             # only the floating-point payload (waveforms, spectrograms) goes to the device: lengths, masks and example counts
             # are read on the host by the model's prompt logic, and a device copy would turn each such read into a stream sync
             # in the middle of a batch (the encoders are running by then)
-            out = {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) and v.is_floating_point() else v)
-                   for k, v in batch.items()}
+            out = copy.copy(batch)     # keeps the batch's own mapping type (CollatedBatch derives its padding masks on demand)
+            out.update({k: v.to(dev, non_blocking=True) for k, v in batch.items()
+                        if isinstance(v, torch.Tensor) and v.is_floating_point()})
         ev = torch.cuda.Event()
         ev.record(side)
         return out, ev, batch          # keep the pinned host batch alive until its copy has been waited for

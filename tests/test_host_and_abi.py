@@ -406,7 +406,9 @@ def test_plugin_boundary_matches_the_reference_signatures():
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "boundary.json")))
     DELIBERATE = {
         # ragged prompts batch on this path and results are batch-invariant: the default is a throughput choice (CLI docstring)
-        ("cli", "batch_size", "default"): (1, 64),
+        ("cli", "batch_size", "default"): (1, None),        # None = auto per model and free HBM (inference.auto_batch_size)
+        # workers share the node's cores with the other ranks: None = usable cores / local ranks - 1, at most 8 (default_num_workers)
+        ("cli", "num_workers", "default"): (4, None),
         # argparse's type=bool turns ANY non-empty string into True ("--interleave False" is True in the reference); _bool parses
         # true/false/1/0 and agrees with the reference on every spelling of True
         ("cli", "randomize_swap", "type"): ("bool", "_bool"), ("cli", "balance_datasets", "type"): ("bool", "_bool"),
