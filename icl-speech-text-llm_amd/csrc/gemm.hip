@@ -774,7 +774,10 @@ static int gemm_impl(const icl_gemm_args* a, void* stream_, const RopeFuse* rope
   else if (tile == 2)
     rc = launch_tile<2, 2, 2, 2>(p, a->batch, stream);
   else if (tile == 3) {
-    ICL_CHECK_ARG(a->split_k == 1, "icl_gemm_bf16: the 256x256 tile does not support split_k");
+    // split-K on the 256x256 tile: every K slice must feed the pipeline's two peeled K-tiles (>= 128 deep), and the slab layout
+    // is that of the other tiles (N % 4 == 0 for the 16-B slab rows of the staged epilogue)
+    ICL_CHECK_ARG(a->split_k == 1 || (a->split_k <= a->K / 128 && a->N % 4 == 0),
+                  "icl_gemm_bf16: split_k=%d on the 256x256 tile needs K / split_k >= 128 and N %% 4 == 0 (K=%d N=%d)", a->split_k, a->K, a->N);
     rc = launch_tile256(p, a->batch, stream);
   } else if (tile == 4 || tile == 6) {   // 6: the same kernel on the decode-packed copy of W
     ICL_CHECK_ARG(a->M <= 64 && a->batch == 1, "icl_gemm_bf16: the skinny kernel needs M <= 64 and batch == 1");

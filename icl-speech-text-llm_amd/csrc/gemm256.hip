@@ -118,9 +118,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p_in, R
   int tm, tn;
   block_to_tile(p, blockIdx.x, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
-  const int z = blockIdx.z;
-  const __bf16* A = p.A + (int64_t)z * p.sA;
-  const int nk = p.K >> 6;
+  // grid.z: batch index, or — split_k > 1 (decode at 129..256 rows: one M-tile, too few N-tiles to fill the chip) — the K slice
+  // [kt0, kt0 + nk) of this block, whose raw f32 partial tile goes to slab z of the workspace (the layout of the other tiles'
+  // split-K: gemm_splitk_reduce_kernel / splitk_reduce_rmsnorm_kernel sum the slabs in slab order and run the epilogue)
+  int z = blockIdx.z;
+  int nk = p.K >> 6, kt0 = 0;
+  if (p.split_k > 1) {
+    kt0 = (int)(((int64_t)z * nk) / p.split_k);
+    nk = (int)(((int64_t)(z + 1) * nk) / p.split_k) - kt0;
+    p.C = p.ws + (int64_t)z * p.M * p.N;
+    p.ldc = p.N;
+    p.sC = 0;
+    p.epi = 0;                 // bias / residual / activation belong to the reduction
+    z = 0;
+  }
+  const __bf16* A = p.A + (int64_t)z * p.sA + (int64_t)kt0 * 64;
+  const __bf16* Wk = p.W + (int64_t)kt0 * 64;
 
   // ---- staging sources: region h, round r -> rows 8*(r*8 + wave) + (lane>>3) of the region -------------------
   const __bf16* gsrc[2][2][2];  // [A|B][region][round]
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p_in, R
       const int row = (r * 8 + wave) * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       gsrc[0][h][r] = A + (int64_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + chunk * 8;
-      gsrc[1][h][r] = p.W + (int64_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + chunk * 8;
+      gsrc[1][h][r] = Wk + (int64_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + chunk * 8;
     }
   auto stage = [&](int bo, int which, int h, int kt) {   // bo: byte offset of the K-tile buffer (0 | T256_BUF); which: 0 = A, 1 = B
     const int64_t koff = (int64_t)min(kt, nk - 1) * 64;
@@ -508,10 +521,11 @@ int iclg::launch_tile256(GemmParams& p, int batch, hipStream_t stream, const Rop
     p.group_m = env_gm > 0 ? env_gm : (int)std::min<int64_t>(6, std::max<int64_t>(1, 8400000 / panel));
     p.xcd_sync = env_xs;
   }
-  const dim3 grid(p.tiles_m * p.tiles_n, 1, batch);
+  const dim3 grid(p.tiles_m * p.tiles_n, 1, p.split_k > 1 ? p.split_k : batch);
   if (rope) return launch256<true, 0>(p, grid, stream, *rope);      // bf16 output, bias-only epilogue (checked by the caller)
   const RopeFuse none{};
   constexpr int G = ICL_EPI_GELU, R = ICL_EPI_RESIDUAL, S = ICL_EPI_SWIGLU, F = T256_OUT_F32;
+  if (p.split_k > 1) return launch256<false, F>(p, grid, stream, none);      // raw f32 partial tiles into the workspace slabs
   switch ((p.epi & (G | R | S)) | (p.out_dtype == ICL_F32 ? F : 0)) {
     case 0:         return launch256<false, 0>(p, grid, stream, none);
     case G:         return launch256<false, G>(p, grid, stream, none);

@@ -132,8 +132,6 @@ def test_gemm_epilogues(B, tile):
 @pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("split_k", [1, 4])
 def test_gemm_swiglu(B, tile, split_k):
-    if tile == 3 and split_k > 1:
-        pytest.skip("the 256x256 tile has no split-K")
     M, I, K = 70, 11008 // 8, 512
     a = _rand_bf16(M, K, seed=6, scale=0.5)
     wg, wu = _rand_bf16(I, K, seed=7, scale=0.1), _rand_bf16(I, K, seed=8, scale=0.1)
@@ -144,6 +142,33 @@ def test_gemm_swiglu(B, tile, split_k):
     B.gemm(a, w, out, swiglu=True, tile=tile, split_k=split_k, workspace=ws)
     ref = torch.nn.functional.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
     assert _relerr(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,split", [(256, 1024, 4160, 5), (256, 512, 4096, 16), (200, 768, 11008, 16), (130, 1000, 832, 3)])
+def test_gemm_256_tile_split_k(B, M, N, K, split):
+    """Split-K on the 256x256 tile (decode at 129..256 rows: one M-tile and too few N-tiles to fill the chip): uneven K slices,
+    edge tiles in M and N, the slabs reduced by the same kernels as the other tiles' — incl. the fused reduce + residual +
+    RMSNorm — so the f32 row must equal tile 2's for the same split (same slab boundaries, same summation order of the slabs;
+    inside a slab the k order differs by kernel: 1e-4)."""
+    a, w = _rand_bf16(M, K, seed=41, scale=0.5), _rand_bf16(N, K, seed=42, scale=0.05)
+    bias, res = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV)
+    ws = torch.empty(split * M * N, device=DEV)
+    out = torch.empty(M, N, device=DEV)
+    B.gemm(a, w, out, bias=bias, residual=res, tile=3, split_k=split, workspace=ws)
+    ref = a.float() @ w.float().t() + bias + res
+    assert (out - ref).abs().max().item() <= 2e-3
+    out2 = torch.empty(M, N, device=DEV)
+    B.gemm(a, w, out2, bias=bias, residual=res, tile=2, split_k=split, workspace=ws)
+    assert (out - out2).abs().max().item() <= 1e-4
+    gamma = 1.0 + 0.1 * torch.randn(N, device=DEV)
+    h, xn = res.clone(), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    B.gemm_rmsnorm(a, w, h, gamma, 1e-5, xn, residual=h, tile=3, split_k=split, workspace=ws)
+    h2 = res.clone()
+    B.gemm(a, w, h2, residual=h2, tile=3, split_k=split, workspace=ws)
+    assert torch.equal(h, h2)
+    assert _relerr(xn, torch.nn.functional.rms_norm(h2, (N,), gamma, 1e-5)) < 4e-3
+    with pytest.raises(B.IclError):
+        B.gemm(a, w, out, tile=3, split_k=K // 64, workspace=torch.empty(K // 64 * M * N, device=DEV))     # slices of one K-tile
 
 
 @pytest.mark.parametrize("M", [1, 16, 32, 64])
