@@ -20,6 +20,10 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef ICL_ATTN_V
+#define ICL_ATTN_V 0       // A/B switches of attn_fwd_kernel (tools/attn_ab.sh): bit 0 = no re-staging in the last AHEAD tiles, bit 1 = heavy-first causal q-blocks
+#endif
+
 namespace {
 
 struct AttnParams {
@@ -104,7 +108,9 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
   const int n_blocks = gridDim.x;
   const int xcd = blockIdx.x & 7, q8 = n_blocks >> 3, r8 = n_blocks & 7;
   const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int qblk = item % p.n_qblocks;
+  // causal: the q-blocks of a (sequence, head) are dealt last-first — block j walks j + 1 K/V tile pairs, so the long blocks of
+  // the launch start first and its tail is made of short ones
+  const int qblk = (CAUSAL && (ICL_ATTN_V & 2)) ? p.n_qblocks - 1 - item % p.n_qblocks : item % p.n_qblocks;
   const int head = (item / p.n_qblocks) % p.n_heads, seq = item / (p.n_qblocks * p.n_heads);
   const int row0 = p.cu[seq];
   const int len = p.cu[seq + 1] - row0;
@@ -220,13 +226,16 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
   // One KV tile.  MAYMASK = false is the interior form: every key of the tile is visible to every query of the wave, so
   // the body carries no mask, no per-q-block branch and none of the key-index arithmetic hipcc otherwise hoists above the
   // "need_mask" test and executes on every tile (35 vector instructions per iteration of the D = 64 kernel).
-  auto tile = [&](const int t, auto maymask_c) {
+  auto tile = [&](const int t, auto maymask_c, auto last_c) {
     constexpr bool MAYMASK = decltype(maymask_c)::value;
-    // unconditional (the last iteration stages its own tile again, into the idle buffer): a conditional issue makes hipcc's
-    // waitcnt pass merge the two paths pessimistically
+    constexpr bool LAST = decltype(last_c)::value;      // one of the last AHEAD tiles: nothing left to stage
+    // unconditional within an instantiation: a run-time condition around the issue makes hipcc's waitcnt pass merge the two
+    // paths pessimistically.  The last AHEAD iterations are their own instantiation WITHOUT the staging (they used to stage
+    // the last tile again into the idle buffer: 2 * NCH LDS-DMA instructions, ~45 ns of issue each, per wave — on the decoders'
+    // prefill, 2-6 tiles per block, that was 17-50 % more staging than the block needs)
     int nxt = cur + AHEAD;
     if (nxt >= NBUF) nxt -= NBUF;
-    stage_tile(min(t + AHEAD, n_tiles - 1), nxt);   // that slot held tile t-1: last read in iteration t-1 (barrier passed)
+    if constexpr (!LAST) stage_tile(min(t + AHEAD, n_tiles - 1), nxt);   // that slot held tile t-1: last read in iteration t-1 (barrier passed)
     const int k0 = t * 64;
     const char* k_lds = lds + cur * BUF;
     const char* v_lds = k_lds + 64 * ROWB;
@@ -419,7 +428,8 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
         }
       }
     }
-    wait_oldest_tile();   // this wave's share of tile t+1 has landed
+    if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing was staged behind tile t+1 (if there is one)
+    else wait_oldest_tile();   // this wave's share of tile t+1 has landed
     // bare s_barrier, not __syncthreads(): the fences of the latter make hipcc drain every LDS-DMA in flight (vmcnt(0)).
     // What the barrier orders is covered by hand: this wave's DMA share of the next tile (counted wait above) and its LDS
     // reads of tile t (every asm read was waited for before the MFMA that consumed it)
@@ -430,12 +440,19 @@ __global__ __launch_bounds__(256, (D == 64 && BIAS) ? 3 : 2) void attn_fwd_kerne
   // the split is per wave, every wave still passes one barrier per tile
   // (with the gated bias too: its interior body is the general path minus the mask and the key-index arithmetic)
   int t = 0;
-  {
+  if constexpr (ICL_ATTN_V & 1) {
+    // the last AHEAD tiles run the general (may-mask) body without staging; need_mask is evaluated per tile there anyway
+    const int n_staged = max(n_tiles - AHEAD, 0);
+    const int n_plain = min(n_staged, CAUSAL ? min(kvlen, qw[0] + 1) >> 6 : kvlen >> 6);
+    for (; t < n_plain; ++t) tile(t, std::false_type{}, std::false_type{});
+    for (; t < n_staged; ++t) tile(t, std::true_type{}, std::false_type{});
+    for (; t < n_tiles; ++t) tile(t, std::true_type{}, std::true_type{});
+  } else {
     const int n_plain = min(n_tiles, CAUSAL ? min(kvlen, qw[0] + 1) >> 6 : kvlen >> 6);
-    for (; t < n_plain; ++t) tile(t, std::false_type{});
+    for (; t < n_plain; ++t) tile(t, std::false_type{}, std::false_type{});
+    for (; t < n_tiles; ++t) tile(t, std::true_type{}, std::false_type{});
   }
-  for (; t < n_tiles; ++t) tile(t, std::true_type{});
-  // the last iterations staged (again) into ring slots the epilogue is about to reuse: every wave's LDS-DMA must have landed
+  // ring slots are about to be reused by the epilogue: every wave's LDS-DMA must have landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 

@@ -9,6 +9,8 @@ Reference call sites: models/custom_salmon.py:546-554 (encode_speech), :115-299 
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -391,33 +393,20 @@ class LlamaHIP:
     decode_packed_weights = True     # micro-batch <= 256: decode GEMMs stream decode-packed copies of the layer weights
     fuse_decode_norms = True         # decode: o_proj / down_proj + the RMSNorm that follows them in one call (icl_gemm_rmsnorm_bf16)
 
-    def __init__(self, w: PackedLlama, device, decode_packed: Optional[bool] = None, pack_now: bool = True):
-        """``decode_packed`` (default: the class attribute): keep a second, decode-packed layout of the layer weights (+12.9 GB
-        at 7B, +25 GB at 13B).  ``pack_now=False`` defers the copy to the first decode step — forward-only users
-        (``forward_logits`` / loss) then never pay for it; the default packs at load time, not inside a caller's first batch."""
-        self.w = w
-        self.device = torch.device(device)
-        self.n_cu = max(B.device_cu_count(), 1)
-        if decode_packed is not None:
-            self.decode_packed_weights = bool(decode_packed)
-        if self.decode_packed_weights and pack_now:
-            self.ensure_decode_packed()
+    # Decode GEMMs at 129..256 rows that run on the 256x256 tile with split-K instead of the decode tile (tile 5).  Measured at the
+    # Llama-2-7B shapes, 256 rows, GEMM + slab reduction (tools/decode_gemm_time.py, profiles/r04_decode_gemm_ab.txt): qkv 54.8 us on
+    # the decode tile -> 46.6 (split 4); o 32.2 -> 29.5 (split 8); gate/up 79.6 -> 67.1 (split 2); down 48.5 -> 49.7: stays.
+    # ICL_DECODE_T256 = comma list of qkv / o / gu / down overrides the set ("" = decode tile only).
+    decode_t256 = tuple(x for x in os.environ.get("ICL_DECODE_T256", "qkv,o,gu").split(",") if x)
 
-    def ensure_decode_packed(self):
-        """Decode-packed copies of the layer weights (second layout of the same bytes: +12.9 GB at 7B, +25 GB at 13B)."""
-        c = self.w.cfg
-        for L in self.w.layers:
-            if getattr(L, "decode_packed", None) is None:
-                L.decode_packed = (B.pack_decode_weights(L.wqkv, K=self.w.k_aug), B.pack_decode_weights(L.wo, K=c.hidden),
-                                   B.pack_decode_weights(L.wgu, K=c.hidden), B.pack_decode_weights(L.wdown, K=c.ffn))
+    def _t256_split(self, N: int, K: int) -> int:
+        """Split-K of a 256-row decode GEMM on the 256x256 tile: one M-tile, ceil(N / 256) N-tiles; the slices fill ~80 % of the
+        CUs (a second partial round of blocks costs more than idle CUs) and stay >= 8 K-tiles deep (the pipeline's fill / drain);
+        0 = leave the GEMM on the decode tile (too few blocks either way)."""
+        tiles = (N + 255) // 256
+        split = min(K // 512, int(0.8 * self.n_cu) // tiles)
+        return split if split >= 2 and tiles * split >= 0.45 * self.n_cu else 0
 
-    # ---- K9 ------------------------------------------------------------------------------------
-    def embed(self, ws: Workspace, src_idx: torch.Tensor, speech: Optional[torch.Tensor], name: str = "ll_h") -> torch.Tensor:
-        h = ws.get(name, (src_idx.numel(), self.w.cfg.hidden), F32)
-        B.embed_gather_interleave(src_idx, self.w.embed, speech, h)
-        return h
-
-    # ---- one decoder layer over M packed rows ---------------------------------------------------
     def _layer(self, ws: Workspace, L, h, M: int, tag: str, attn_fn, pos, seq_ids, kc, vc, max_len: int,
                split: Optional[dict] = None, kv_rows_to_c: bool = True, xn_ready: bool = False, next_norm=None):
         """``xn_ready``: the previous call has already written this layer's normalised input (decode: fused into the reduction
@@ -431,8 +420,18 @@ class LlamaHIP:
         att = ws.get(tag + "att", (M, hd), BF16)
         act = ws.get(tag + "act", (M, I), BF16)
         sk = split or {}
-        nsplit = max([v for k, v in sk.items() if k != "tile"], default=1)
+
+        def tile_of(name):          # per-GEMM kernel choice of a decode step ("tile_qkv" ...), else the step's common one
+            return sk.get("tile_" + name, sk.get("tile", 0))
+
+        def weight_of(name, idx, row_major):       # the decode tiles (5 / 6) stream the decode-packed copy, every other tile the original
+            return L.decode_packed[idx] if tile_of(name) in (5, 6) else row_major
+        nsplit = max([v for k, v in sk.items() if not k.startswith("tile")], default=1)
         wsk = ws.get(tag + "splitk", (nsplit * M * max(3 * hd, 2 * I),), F32) if nsplit > 1 else None
+        if wsk is None and sk.get("tile") in (4, 6):
+            # <= 8 decode rows: the skinny GEMMs behind o_proj / down_proj run their RMSNorm in the block that finishes last
+            # (icl_gemm_rmsnorm_bf16); this word is that launch's ticket counter (zero between launches)
+            wsk = ws.get(tag + "ticket", (64,), F32, zero=True)
         if not xn_ready:
             B.rmsnorm(h, L.rms1, xn, c.rms_eps, N=hd)
         if L.lora_a is not None:   # x_aug[:, hd:hd+2r] = x @ (s*A)^T : a skinny GEMM for prefill, a GEMV-style kernel for decode
@@ -449,27 +448,26 @@ class LlamaHIP:
             B.gemm(xn, L.wqkv, qkv, bias=L.bqkv, tile=3,
                    rope=(hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, kv_rows_to_c))
         else:
-            B.gemm(xn, L.decode_packed[0] if sk.get("tile") in (5, 6) else L.wqkv, qkv, bias=L.bqkv, split_k=sk.get("qkv", 1),
-                   workspace=wsk, tile=sk.get("tile", 0), N=3 * hd, K=w.k_aug)
+            B.gemm(xn, weight_of("qkv", 0, L.wqkv), qkv, bias=L.bqkv, split_k=sk.get("qkv", 1),
+                   workspace=wsk, tile=tile_of("qkv"), N=3 * hd, K=w.k_aug)
             B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
         attn_fn(qkv, att)
-        dp = L.decode_packed if sk.get("tile") in (5, 6) else None    # (wqkv, wo, wgu, wdown) in the decode kernels' layout
         fuse = split is not None and self.fuse_decode_norms
         if fuse:     # decode: h += att Wo^T and the post-attention RMSNorm in one call (one kernel when the GEMM is split-K)
-            B.gemm_rmsnorm(att, dp[1] if dp else L.wo, h, L.rms2, c.rms_eps, xn, residual=h, split_k=sk.get("o", 1),
-                           workspace=wsk, tile=sk.get("tile", 0), N=hd, K=hd)
+            B.gemm_rmsnorm(att, weight_of("o", 1, L.wo), h, L.rms2, c.rms_eps, xn, residual=h, split_k=sk.get("o", 1),
+                           workspace=wsk, tile=tile_of("o"), N=hd, K=hd)
         else:
-            B.gemm(att, dp[1] if dp else L.wo, h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=sk.get("tile", 0),
+            B.gemm(att, weight_of("o", 1, L.wo), h, residual=h, split_k=sk.get("o", 1), workspace=wsk, tile=tile_of("o"),
                    N=hd, K=hd)
             B.rmsnorm(h, L.rms2, xn, c.rms_eps, N=hd)
-        B.gemm(xn, dp[2] if dp else L.wgu, act, swiglu=True, K=hd, split_k=sk.get("gu", 1), workspace=wsk,
-               tile=sk.get("tile", 0), N=2 * I)
+        B.gemm(xn, weight_of("gu", 2, L.wgu), act, swiglu=True, K=hd, split_k=sk.get("gu", 1), workspace=wsk,
+               tile=tile_of("gu"), N=2 * I)
         if fuse and next_norm is not None:
-            B.gemm_rmsnorm(act, dp[3] if dp else L.wdown, h, next_norm[0], c.rms_eps, next_norm[1], residual=h,
-                           split_k=sk.get("down", 1), workspace=wsk, tile=sk.get("tile", 0), N=hd, K=I)
+            B.gemm_rmsnorm(act, weight_of("down", 3, L.wdown), h, next_norm[0], c.rms_eps, next_norm[1], residual=h,
+                           split_k=sk.get("down", 1), workspace=wsk, tile=tile_of("down"), N=hd, K=I)
             return True
-        B.gemm(act, dp[3] if dp else L.wdown, h, residual=h, split_k=sk.get("down", 1), workspace=wsk,
-               tile=sk.get("tile", 0), N=hd, K=I)
+        B.gemm(act, weight_of("down", 3, L.wdown), h, residual=h, split_k=sk.get("down", 1), workspace=wsk,
+               tile=tile_of("down"), N=hd, K=I)
         return False
 
     # ---- K10: prefill over ragged packed sequences ------------------------------------------------
@@ -546,6 +544,12 @@ class LlamaHIP:
             else:
                 split = dict(qkv=sk5(3 * c.hidden, self.w.k_aug), o=sk5(c.hidden, c.hidden), gu=sk5(2 * c.ffn, c.hidden),
                              down=sk5(c.hidden, c.ffn), tile=5)
+                if Bn > 128:
+                    for name, (N, K) in (("qkv", (3 * c.hidden, self.w.k_aug)), ("o", (c.hidden, c.hidden)),
+                                         ("gu", (2 * c.ffn, c.hidden)), ("down", (c.hidden, c.ffn))):
+                        s256 = self._t256_split(N, K) if name in self.decode_t256 else 0
+                        if s256:
+                            split[name], split["tile_" + name] = s256, 3
         elif Bn <= 8:
             split = dict(tile=4)
         else:

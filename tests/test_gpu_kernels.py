@@ -813,7 +813,8 @@ def test_gemm_m128_decode_kernel(B, M, N, K, split):
 
 
 @pytest.mark.parametrize("M,N,K,split,tile", [(256, 4096, 1024, 8, 5), (130, 4096, 2048, 4, 5), (37, 5120, 1024, 2, 5), (256, 4096, 512, 1, 5),
-                                              (300, 4096, 1024, 4, 2), (5, 4096, 1024, 1, 6), (5, 4096, 1024, 2, 6), (33, 4096, 1024, 4, 4)])
+                                              (300, 4096, 1024, 4, 2), (5, 4096, 1024, 1, 6), (5, 4096, 1024, 2, 6), (33, 4096, 1024, 4, 4), (1, 4096, 4096, 1, 6),
+                                              (8, 4096, 11008, 1, 6), (40, 4096, 512, 1, 4)])
 def test_gemm_rmsnorm_decode_fusion(B, M, N, K, split, tile):
     """icl_gemm_rmsnorm_bf16 (decode: projection back into the residual stream + the RMSNorm that follows, the split-K
     reduction, residual add, row store and normalisation in ONE kernel): the f32 row must be bit-identical to icl_gemm_bf16
@@ -834,6 +835,16 @@ def test_gemm_rmsnorm_decode_fusion(B, M, N, K, split, tile):
     xn = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device=DEV)
     B.gemm_rmsnorm(a, wt, h, gamma, 1e-5, xn, residual=h, tile=tile, split_k=split, workspace=ws, N=N)
     assert torch.equal(h, h_ref)
+    if tile in (4, 6) and split == 1:
+        # with a ticket word the skinny launch runs the norm itself, in the block that finishes last: same h, xn as icl_rmsnorm
+        # writes it (N = 4096: the one-wave-per-row arithmetic), the ticket back at zero — several launches in a row
+        ticket = torch.zeros(64, device=DEV)
+        for _ in range(3):
+            h2 = res.clone()
+            xn2 = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device=DEV)
+            B.gemm_rmsnorm(a, wt, h2, gamma, 1e-5, xn2, residual=h2, tile=tile, split_k=1, workspace=ticket, N=N)
+            assert torch.equal(h2, h_ref) and torch.equal(xn2[:, :N], xn_ref[:, :N]) and float(ticket.abs().sum()) == 0.0
+            assert bool((xn2[:, N:] == 7.0).all())
     assert bool((xn[:, N:] == 7.0).all())                          # the LoRA augmentation columns are not touched
     d = (xn[:, :N].float() - xn_ref[:, :N].float()).abs()
     ulp = xn_ref[:, :N].float().abs() * 2.0 ** -7

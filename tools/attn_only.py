@@ -12,6 +12,7 @@ B.load_library()
 which = sys.argv[1] if len(sys.argv) > 1 else "whisper"
 nseq, L, H, D, causal = {"whisper": (64, 1500, 20, 64, False), "llama": (64, 376, 32, 128, True), "beats": (64, 1496, 12, 64, False),
                          "beats_bias": (64, 1496, 12, 64, False)}[which]
+nseq = int(os.environ.get("ICL_ATTN_NSEQ", nseq))
 total = nseq * L
 qkv = torch.randn(total, 3 * H * D, device=DEV).to(torch.bfloat16)
 out = torch.empty(total, H * D, dtype=torch.bfloat16, device=DEV)
