@@ -334,41 +334,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(GemmParams p
 // (M x K, <= 0.7 MB) are re-read by every block from L2.  MB = 16-row blocks of M, NT = 16-column tiles per block
 // (2 for the SwiGLU epilogue so a gate block and its up block meet in one lane).
 // =================================================================================================================
-// Tail of a skinny launch (decode at <= 64 rows): work that needs the WHOLE finished rows and used to be the next launch — the
-// RMSNorm behind o_proj / down_proj (8.7 us as a launch of its own at one row; a decode step of one sequence is a chain of 9
-// such small launches per layer).  Every block publishes its columns (stores, device-scope fence, one ticket); the block that
-// draws the last ticket has, after its own acquire fence, every column of every row in front of it and runs the tail — one wave
-// per row, the arithmetic of norm_kernel (4-element chunks lane + 64 i in ascending i, shuffle reduction), so xn is what
-// icl_rmsnorm writes for the N <= 4096 row shapes and within the fused split-K path's tolerance (summation order) otherwise.
-// No block ever waits for another (a ticket, not a barrier); the last block leaves the ticket at zero for the next launch.
-struct SkinnyTail {
-  unsigned* ticket;      // nullptr: no tail
-  const float* gamma;
-  unsigned short* xn;
-  int64_t ldx;
-  float eps;
-};
-
-__device__ __forceinline__ void skinny_tail_rmsnorm(const GemmParams& p, const SkinnyTail& tl, int wave, int lane) {
-  const int nvec = p.N >> 2;
-  for (int m = wave; m < p.M; m += 8) {
-    const float* row = (const float*)p.C + (int64_t)m * p.ldc;
-    float ss = 0.f;
-    for (int c = lane; c < nvec; c += 64) {
-      const f32x4 v = *(const f32x4*)(row + c * 4);
-      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-    }
-    const float rstd = rsqrtf(wave_reduce_sum(ss) / (float)p.N + tl.eps);
-    for (int c = lane; c < nvec; c += 64) {
-      const f32x4 v = *(const f32x4*)(row + c * 4), g = *(const f32x4*)(tl.gamma + c * 4);
-      const f32x4 o = v * rstd * g;
-      *(u32x2*)(tl.xn + (int64_t)m * tl.ldx + c * 4) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-    }
-  }
-}
-
 template <int MB, int NT, int U, bool PACKED>   // PACKED: W is the decode-packed copy (tile 6): a wave-load is 1 KB contiguous
-__global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmParams p, SkinnyTail tl) {
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmParams p) {
   __shared__ float red[8][NT][MB][256];   // [wave][n-tile][m-block][lane*4 + r]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -446,25 +413,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmParams p, SkinnyTa
       }
     }
   }
-  if (tl.ticket) {
-    __shared__ int is_last;
-    __threadfence();                       // release: this thread's stores of C are visible device-wide before the ticket is drawn
-    __syncthreads();
-    if (tid == 0) is_last = atomicAdd(tl.ticket, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (is_last) {
-      __threadfence();                     // acquire: the other blocks' columns
-      if (tid == 0) *tl.ticket = 0u;       // the next launch on the stream finds the ticket at zero
-      skinny_tail_rmsnorm(p, tl, wave, lane);
-    }
-  }
 }
 
 template <int MB, int NT, int U>
-int launch_skinny(GemmParams& p, hipStream_t stream, bool packed, const SkinnyTail& tl = SkinnyTail{}) {
+int launch_skinny(GemmParams& p, hipStream_t stream, bool packed) {
   const int blocks = (p.N + 16 * NT - 1) / (16 * NT);
-  if (packed) hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, true>), dim3(blocks), dim3(512), 0, stream, p, tl);
-  else        hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, false>), dim3(blocks), dim3(512), 0, stream, p, tl);
+  if (packed) hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, true>), dim3(blocks), dim3(512), 0, stream, p);
+  else        hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, false>), dim3(blocks), dim3(512), 0, stream, p);
   ICL_CHECK_LAUNCH("icl_gemm_bf16(skinny)");
   return ICL_OK;
 }
@@ -734,7 +689,11 @@ extern "C" int icl_gemm_select_tile(int32_t M, int32_t N, int32_t K, int32_t bat
   const int64_t t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch;
   const int64_t rounds = (t256 + ncu - 1) / ncu;
   const double eff = (double)t256 / (double)(rounds * ncu);
-  if (K >= 768 && eff >= 0.8) return 3;   // measured at micro-batch 128: the 256x256 tile wins from K = 768 (BEATs) upwards
+  // measured at micro-batch 128: the 256x256 tile wins from K = 768 (BEATs) upwards.  One partial round of 256-tiles still beats
+  // two rounds of 128-tiles down to ~60 % of the CUs (one utterance's gate/up, 376 x 22016 x 4096: 172 tiles, 76 us vs 115 us on
+  // the 128-tile; at 96 tiles — its QKV projection — the 128-tile wins 67 vs 71 us; tools/gemm_small_m.py, round 4).  Tiles 1 - 3
+  // sum K in the same order, so the choice never changes a row's bits.
+  if (K >= 768 && eff >= 0.6) return 3;
   return 1;
 }
 
@@ -829,13 +788,8 @@ static int gemm_impl(const icl_gemm_args* a, void* stream_, const RopeFuse* rope
     p.split_k = 1;   // K is split inside the block
     const bool sw = a->epilogue & ICL_EPI_SWIGLU, pk = tile == 6;
     const int mb = (a->M + 15) / 16;
-    SkinnyTail tl{};
-    if (norm) {      // icl_gemm_rmsnorm_bf16 with a ticket word: the RMSNorm runs in the block that finishes last (validated by the caller)
-      tl.ticket = (unsigned*)a->workspace;
-      tl.gamma = norm->gamma; tl.xn = norm->xn; tl.ldx = norm->ldx; tl.eps = norm->eps;
-    }
-    if (sw) rc = mb <= 1 ? launch_skinny<1, 2, 4>(p, stream, pk, tl) : mb == 2 ? launch_skinny<2, 2, 2>(p, stream, pk, tl) : launch_skinny<4, 2, 2>(p, stream, pk, tl);
-    else    rc = mb <= 1 ? launch_skinny<1, 1, 8>(p, stream, pk, tl) : mb == 2 ? launch_skinny<2, 1, 4>(p, stream, pk, tl) : launch_skinny<4, 1, 2>(p, stream, pk, tl);
+    if (sw) rc = mb <= 1 ? launch_skinny<1, 2, 4>(p, stream, pk) : mb == 2 ? launch_skinny<2, 2, 2>(p, stream, pk) : launch_skinny<4, 2, 2>(p, stream, pk);
+    else    rc = mb <= 1 ? launch_skinny<1, 1, 8>(p, stream, pk) : mb == 2 ? launch_skinny<2, 1, 4>(p, stream, pk) : launch_skinny<4, 1, 2>(p, stream, pk);
     return rc;
   } else if (tile == 5) {
     ICL_CHECK_ARG(a->M <= 256 && a->batch == 1, "icl_gemm_bf16: the decode tile needs M <= 256 and batch == 1");
@@ -880,12 +834,9 @@ extern "C" int icl_gemm_rmsnorm_bf16(const icl_gemm_args* a, const float* gamma,
     const NormFuse nf{gamma, eps, (unsigned short*)xn, ld_xn};
     return gemm_impl(a, stream, nullptr, &nf);
   }
-  // tiles 4 / 6 with a workspace: its first word is the launch's ticket counter (zero on entry, zero again on exit) and the
-  // RMSNorm runs inside the GEMM launch, in the block that finishes last (SkinnyTail)
-  if ((a->tile == 4 || a->tile == 6) && a->split_k == 1 && a->workspace && a->M <= 64 && ((uintptr_t)a->workspace & 3) == 0) {
-    const NormFuse nf{gamma, eps, (unsigned short*)xn, ld_xn};
-    return gemm_impl(a, stream, nullptr, &nf);
-  }
+  // (Round 4 tried running this norm inside the skinny launch, in the block that draws the last of one ticket per block — correct,
+  // and 6-8 us SLOWER per call than the second launch inside a HIP graph: the device-scope release fence in front of the ticket
+  // is an L2 write-back; tools/skinny_tail_time.py)
   const int rc = gemm_impl(a, stream, nullptr);            // no slabs to reduce: the GEMM's own epilogue, then the plain norm
   if (rc != ICL_OK) return rc;
   return icl_rmsnorm(a->C, a->ldc, gamma, xn, ld_xn, a->M, a->N, eps, ICL_F32, ICL_BF16, stream);

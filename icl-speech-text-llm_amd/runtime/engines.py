@@ -407,6 +407,33 @@ class LlamaHIP:
         split = min(K // 512, int(0.8 * self.n_cu) // tiles)
         return split if split >= 2 and tiles * split >= 0.45 * self.n_cu else 0
 
+    def __init__(self, w: PackedLlama, device, decode_packed: Optional[bool] = None, pack_now: bool = True):
+        """``decode_packed`` (default: the class attribute): keep a second, decode-packed layout of the layer weights (+12.9 GB
+        at 7B, +25 GB at 13B).  ``pack_now=False`` defers the copy to the first decode step — forward-only users
+        (``forward_logits`` / loss) then never pay for it; the default packs at load time, not inside a caller's first batch."""
+        self.w = w
+        self.device = torch.device(device)
+        self.n_cu = max(B.device_cu_count(), 1)
+        if decode_packed is not None:
+            self.decode_packed_weights = bool(decode_packed)
+        if self.decode_packed_weights and pack_now:
+            self.ensure_decode_packed()
+
+    def ensure_decode_packed(self):
+        """Decode-packed copies of the layer weights (second layout of the same bytes: +12.9 GB at 7B, +25 GB at 13B)."""
+        c = self.w.cfg
+        for L in self.w.layers:
+            if getattr(L, "decode_packed", None) is None:
+                L.decode_packed = (B.pack_decode_weights(L.wqkv, K=self.w.k_aug), B.pack_decode_weights(L.wo, K=c.hidden),
+                                   B.pack_decode_weights(L.wgu, K=c.hidden), B.pack_decode_weights(L.wdown, K=c.ffn))
+
+    # ---- K9 ------------------------------------------------------------------------------------
+    def embed(self, ws: Workspace, src_idx: torch.Tensor, speech: Optional[torch.Tensor], name: str = "ll_h") -> torch.Tensor:
+        h = ws.get(name, (src_idx.numel(), self.w.cfg.hidden), F32)
+        B.embed_gather_interleave(src_idx, self.w.embed, speech, h)
+        return h
+
+    # ---- one decoder layer over M packed rows ---------------------------------------------------
     def _layer(self, ws: Workspace, L, h, M: int, tag: str, attn_fn, pos, seq_ids, kc, vc, max_len: int,
                split: Optional[dict] = None, kv_rows_to_c: bool = True, xn_ready: bool = False, next_norm=None):
         """``xn_ready``: the previous call has already written this layer's normalised input (decode: fused into the reduction
@@ -428,10 +455,6 @@ class LlamaHIP:
             return L.decode_packed[idx] if tile_of(name) in (5, 6) else row_major
         nsplit = max([v for k, v in sk.items() if not k.startswith("tile")], default=1)
         wsk = ws.get(tag + "splitk", (nsplit * M * max(3 * hd, 2 * I),), F32) if nsplit > 1 else None
-        if wsk is None and sk.get("tile") in (4, 6):
-            # <= 8 decode rows: the skinny GEMMs behind o_proj / down_proj run their RMSNorm in the block that finishes last
-            # (icl_gemm_rmsnorm_bf16); this word is that launch's ticket counter (zero between launches)
-            wsk = ws.get(tag + "ticket", (64,), F32, zero=True)
         if not xn_ready:
             B.rmsnorm(h, L.rms1, xn, c.rms_eps, N=hd)
         if L.lora_a is not None:   # x_aug[:, hd:hd+2r] = x @ (s*A)^T : a skinny GEMM for prefill, a GEMV-style kernel for decode

@@ -101,10 +101,8 @@ int icl_gemm_bf16(const icl_gemm_args* args, void* stream);
  * (epilogue must be 0 or ICL_EPI_RESIDUAL with an f32 residual, batch 1, f32 output) AND xn[m][:N] = bf16(rmsnorm(C[m]) * gamma).
  * With split_k > 1 the partial slabs are reduced, the residual added, the row stored and normalised by ONE kernel (a launch
  * and a re-read of the row less than icl_gemm_bf16 + icl_rmsnorm; C is bit-identical to that pair, xn sums its squares in a
- * different — fixed — order); with split_k == 1 it is exactly that pair — except on tiles 4 / 6 (M <= 64, split_k == 1) WITH a workspace:
- * its first 32-bit word is then the launch's ticket counter (zero on entry; the kernel leaves it zero), every block publishes
- * its columns and draws a ticket, and the block that draws the last one runs the RMSNorm of all rows inside the same launch
- * (no block waits for another).  tile 3 accepts split_k > 1 since ABI 5 (K / split_k >= 128).  No reference counterpart (fusion). */
+ * different — fixed — order); with split_k == 1 it is exactly that pair.  tile 3 accepts split_k > 1 since ABI 5
+ * (K / split_k >= 128).  No reference counterpart (fusion). */
 int icl_gemm_rmsnorm_bf16(const icl_gemm_args* args, const float* gamma, float eps, void* xn, int64_t ld_xn, void* stream);
 /* Decode-packed copy of a weight matrix for tile 5: row-major bf16 W [N][ldw] -> out, (ceil(N/16)*16) x K bf16
  * elements: per 16-row block a K-long stream of 1-KB pieces (one per 32-wide k-step) in MFMA operand order, so that the

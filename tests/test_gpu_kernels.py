@@ -835,16 +835,6 @@ def test_gemm_rmsnorm_decode_fusion(B, M, N, K, split, tile):
     xn = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device=DEV)
     B.gemm_rmsnorm(a, wt, h, gamma, 1e-5, xn, residual=h, tile=tile, split_k=split, workspace=ws, N=N)
     assert torch.equal(h, h_ref)
-    if tile in (4, 6) and split == 1:
-        # with a ticket word the skinny launch runs the norm itself, in the block that finishes last: same h, xn as icl_rmsnorm
-        # writes it (N = 4096: the one-wave-per-row arithmetic), the ticket back at zero — several launches in a row
-        ticket = torch.zeros(64, device=DEV)
-        for _ in range(3):
-            h2 = res.clone()
-            xn2 = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device=DEV)
-            B.gemm_rmsnorm(a, wt, h2, gamma, 1e-5, xn2, residual=h2, tile=tile, split_k=1, workspace=ticket, N=N)
-            assert torch.equal(h2, h_ref) and torch.equal(xn2[:, :N], xn_ref[:, :N]) and float(ticket.abs().sum()) == 0.0
-            assert bool((xn2[:, N:] == 7.0).all())
     assert bool((xn[:, N:] == 7.0).all())                          # the LoRA augmentation columns are not touched
     d = (xn[:, :N].float() - xn_ref[:, :N].float()).abs()
     ulp = xn_ref[:, :N].float().abs() * 2.0 ** -7
