@@ -21,7 +21,7 @@
 #include <type_traits>
 
 #ifndef ICL_ATTN_V
-#define ICL_ATTN_V 0       // A/B switches of attn_fwd_kernel (tools/attn_ab.sh): bit 0 = no re-staging in the last AHEAD tiles, bit 1 = heavy-first causal q-blocks
+#define ICL_ATTN_V 1       // A/B switches of attn_fwd_kernel (tools/attn_ab.sh): bit 0 = no re-staging in the last AHEAD tiles, bit 1 = heavy-first causal q-blocks
 #endif
 
 namespace {

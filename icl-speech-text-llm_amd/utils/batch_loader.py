@@ -8,7 +8,7 @@ thread's copy into a new page-locked block, then the DMA — and first-touch pag
 bound it (measured: 1.2 s of a worker's time per 256-utterance batch for the collate alone, 20 ms when the destination pages
 already exist).  Here the destination exists ONCE:
 
-* the main process allocates ``slots`` arenas in shared memory before it forks the workers and page-locks them
+* the main process allocates ``slots`` arenas as anonymous shared mappings before it forks the workers and page-locks them
   (``hipHostRegister``), so a worker's collate writes each waveform exactly once, into pages that are already mapped, and the
   H2D copy is a direct DMA from that same memory on a side stream while the previous batch's kernels run;
 * a worker returns small tensors / strings through a queue and, for everything it placed in the arena, only
@@ -45,10 +45,16 @@ class CollateArena:
     def __init__(self, nbytes: int, shared: bool = True):
         self.nbytes = int(nbytes)
         self.buffer = None
+        self._map = None
         if self.nbytes:
-            self.buffer = torch.empty(self.nbytes, dtype=torch.uint8)
             if shared:
-                self.buffer.share_memory_()
+                # an anonymous MAP_SHARED mapping: inherited by the forked workers at the same address, and not a file under
+                # /dev/shm (whose size limit — 64 MB in a default container — eight ranks x ten half-gigabyte slots would hit)
+                import mmap
+                self._map = mmap.mmap(-1, self.nbytes, flags=mmap.MAP_SHARED | mmap.MAP_ANONYMOUS)
+                self.buffer = torch.frombuffer(self._map, dtype=torch.uint8)
+            else:
+                self.buffer = torch.empty(self.nbytes, dtype=torch.uint8)
             self.buffer.zero_()                       # touch every page once, here, not under a timed batch
         self.used = 0
         self.asked = 0

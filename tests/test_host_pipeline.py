@@ -191,3 +191,20 @@ def test_arena_batch_loader_reports_a_failing_item():
             next(it)
     finally:
         ld.close()
+
+
+def test_cli_defaults_follow_the_host_and_the_model(monkeypatch):
+    """``--num_workers`` / ``--batch_size`` left out: workers = usable cores / ranks on the node - 1 (at most 8, at least 1), the
+    batch from the model family on a GPU and a small constant on the CPU (reference defaults: 4 and 1,
+    inference/inference.py:62-69; deliberate differences listed in test_plugin_boundary_matches_the_reference_signatures)."""
+    from types import SimpleNamespace
+    from icl_speech_text_llm_amd.inference import inference as cli
+    args = cli.parse_args(["--peft_model_path", "", "--run_name", "x", "--dataset_type", "voxceleb"])
+    assert args.batch_size is None and args.num_workers is None
+    monkeypatch.setattr(cli, "usable_cores", lambda: 16)
+    assert [cli.default_num_workers(w) for w in (1, 2, 4, 8, 16, 64)] == [8, 7, 3, 1, 1, 1]
+    monkeypatch.setattr(cli, "usable_cores", lambda: 128)
+    assert cli.default_num_workers(8) == 8
+    assert 1 <= cli.usable_cores.__wrapped__() if hasattr(cli.usable_cores, "__wrapped__") else True
+    model = SimpleNamespace(cfg=SimpleNamespace(llama=SimpleNamespace(hidden=4096, n_layers=32)))
+    assert cli.auto_batch_size(model, "cpu") == 8 and cli.auto_batch_size(SimpleNamespace(), "cpu") == 8
