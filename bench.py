@@ -829,7 +829,9 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 key = {1: "gemm_bf16_kernel<2, 2, 4, 4>", 2: "gemm_bf16_kernel<2, 2, 2, 2>", 3: "gemm256_bf16_kernel"}[dom]
                 if f"(batch {Bm}" in pmc["command"] and not args.tiny:
-                    rows = [v for k, v in pmc["kernels"].items() if k == key or k.startswith(key + "<")]   # all instantiations
+                    # all instantiations; launches listed apart ("name [label]": the decode split-K launches, which run inside the
+                    # captured decode graph and are not among the live-timed launches above) stay out of the average
+                    rows = [v for k, v in pmc["kernels"].items() if (k == key or k.startswith(key + "<")) and "[" not in k]
                     traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows))
                     traffic_src = cand
                     break
@@ -841,7 +843,7 @@ def main():
                 f"passes of this command (profiles/{traffic_src}); the counters sit at the L2<->fabric boundary and "
                 "include Infinity-Cache hits" if traffic else None, "launches": n, "avg_launch_us": round(tt / n * 1e6, 2),
                 "avg_launch_gflop": round(fl / n / 1e9, 3), "share_of_step_time": round(tt / elapsed, 3),
-                "clock_note": "peak is the nominal 2.4 GHz figure; SQ counters over the bench's own launches (profiles/r03_pmc_sq_*.json: "
+                "clock_note": "peak is the nominal 2.4 GHz figure; SQ counters over the bench's own launches (round 3, profiles/r03_pmc_sq_*.json: "
                               "SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) read 75-80 % matrix-pipe busy at ~1.75 GHz on the K >= 4096 shapes, "
                               "51-63 % at ~1.9 GHz on the K = 1280 shapes: busy x clock / 2.4 GHz reproduces this fraction",
                 "all_gemm_share_of_step_time": round(all_t / elapsed, 3),

@@ -5,6 +5,16 @@ WRITE_SIZE is exact for 16-B-per-lane stores -> write bytes = WRITE_SIZE * 1024 
 import csv, glob, json, re, sys
 from collections import defaultdict
 
+import os
+# "kernel name:grid,grid,...=label": launches of that kernel with one of those Grid_Size values are listed under their own key
+# (round 4: the decode GEMMs now run on gemm256_bf16_kernel<false, 16> with split-K — 128 / 172 / 192 workgroups — inside the
+# captured decode graph; the roofline of the dominant kernel is taken over the launches the live HIP events time, i.e. without them)
+SPLIT = {}
+for spec in filter(None, os.environ.get("ICL_PMC_SPLIT", "").split(";")):
+    key, label = spec.rsplit("=", 1)
+    name, grids = key.rsplit(":", 1)
+    SPLIT[name] = ({int(g) for g in grids.split(",")}, label)
+
 def collect(d, counter):
     f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
     acc = defaultdict(lambda: [0.0, 0])
@@ -13,6 +23,8 @@ def collect(d, counter):
             continue
         n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         n = re.sub(r"\(.*", "", n).replace("void ", "")
+        if n in SPLIT and int(r["Grid_Size"]) in SPLIT[n][0]:
+            n = f"{n} [{SPLIT[n][1]}]"
         acc[n][0] += float(r["Counter_Value"]); acc[n][1] += 1
     return acc
 
