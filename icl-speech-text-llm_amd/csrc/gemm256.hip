@@ -9,6 +9,16 @@
 
 using namespace iclg;
 
+#ifndef ICL_EPI_NT
+// Non-temporal loads / stores in the staged epilogue (round 4): an output tile is written once and read by a LATER launch, after
+// gigabytes of other traffic, and the f32 residual is read once — kept out of the caches they stop evicting the A / W panels the
+// main loops of the other CUs re-read (Whisper o +3.5 %, qkv +2.2 %, Llama gate/up +1.4 % in tools/gemm_ab.py; in situ -5.5 ms
+// of a 1791 ms step: the consumer of an output loses the few Infinity-Cache hits it had; profiles/r04_gemm_nt_ab.txt).
+// bit 0 = the f32 residual stream (load + store), bit 1 = the other staged tiles (not split-K slabs: their reduction re-reads
+// them immediately), bit 2 = the fused RoPE epilogue's stores (measured: no difference, off).
+#define ICL_EPI_NT 3
+#endif
+
 namespace {
 
 // =================================================================================================================
@@ -31,6 +41,11 @@ constexpr int T256_BUF = 4 * T256_REGION;       // A0 A1 B0 B1
 constexpr int T256_SMEM = 256 * (256 * 2 + 16);   // 135168: the two K-tile buffers (131072) / the C staging of the epilogue
                                                   // (whole bf16 tile, or one 128-row half in f32: 133120)
 
+__device__ __forceinline__ void st16(unsigned short* dst, u32x4 v) {      // a 16-B piece of a staged output row
+  if (ICL_EPI_NT & 4) __builtin_nontemporal_store(v, (u32x4*)dst);
+  else *(u32x4*)dst = v;
+}
+
 __device__ __forceinline__ void rope_rows(const GemmParams& p, const RopeFuse& rf, const char* smem, int pitch, int m0,
                                           int n0, int tid) {
   const int sect = n0 >= rf.v_off ? 2 : (n0 >= rf.k_off ? 1 : 0);
@@ -52,8 +67,8 @@ __device__ __forceinline__ void rope_rows(const GemmParams& p, const RopeFuse& r
         const int c = base + u * 512, row = c >> 5, cc = c & 31, m = m0 + row;
         if (m >= p.M) continue;
         const u32x4 v = *(const u32x4*)(smem + row * pitch + cc * 16);
-        if (rf.kv_rows_to_c) *(u32x4*)(C + (int64_t)m * p.ldc + n0 + cc * 8) = v;
-        if (rf.vc) *(u32x4*)(rf.vc + (crow[u] + (int64_t)(head0 + (cc >> 4)) * rf.max_len) * 128 + (cc & 15) * 8) = v;
+        if (rf.kv_rows_to_c) st16(C + (int64_t)m * p.ldc + n0 + cc * 8, v);
+        if (rf.vc) st16(rf.vc + (crow[u] + (int64_t)(head0 + (cc >> 4)) * rf.max_len) * 128 + (cc & 15) * 8, v);
       }
     }
     return;
@@ -90,13 +105,13 @@ __device__ __forceinline__ void rope_rows(const GemmParams& p, const RopeFuse& r
       rope_rot8(lo[u], hi[u], c0[u], c1[u], s0[u], s1[u], olo, ohi);
       if (sect == 0 || rf.kv_rows_to_c) {
         unsigned short* dst = C + (int64_t)m * p.ldc + n0 + hh * 128 + j * 8;
-        *(u32x4*)dst = olo;
-        *(u32x4*)(dst + 64) = ohi;
+        st16(dst, olo);
+        st16(dst + 64, ohi);
       }
       if (to_cache) {
         unsigned short* cd = rf.kc + (((int64_t)sq[u] * rf.H + head0 + hh) * rf.max_len + ps[u]) * 128 + j * 8;
-        *(u32x4*)cd = olo;
-        *(u32x4*)(cd + 64) = ohi;
+        st16(cd, olo);
+        st16(cd + 64, ohi);
       }
     }
   }
@@ -123,6 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p_in, R
   // split-K: gemm_splitk_reduce_kernel / splitk_reduce_rmsnorm_kernel sum the slabs in slab order and run the epilogue)
   int z = blockIdx.z;
   int nk = p.K >> 6, kt0 = 0;
+  const bool slab_out = p.split_k > 1;      // split-K slabs are re-read by the reduction right away: ordinary (cacheable) stores
   if (p.split_k > 1) {
     kt0 = (int)(((int64_t)z * nk) / p.split_k);
     nk = (int)(((int64_t)(z + 1) * nk) / p.split_k) - kt0;
@@ -348,7 +364,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p_in, R
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int c = tid + it * 512, row = c >> 6, cc = c & 63;
-        rr[it] = *(const f32x4*)(rbase + (int64_t)row * p.ldr * 4 + cc * 16);
+        rr[it] = ICL_EPI_NT & 1 ? __builtin_nontemporal_load((const f32x4*)(rbase + (int64_t)row * p.ldr * 4 + cc * 16))
+                                : *(const f32x4*)(rbase + (int64_t)row * p.ldr * 4 + cc * 16);
       }
     };
     if (has_res) load_res_rows(0, rrA);
@@ -398,7 +415,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p_in, R
         for (int it = 0; it < 16; ++it) {
           const int c = tid + it * 512, row = c >> 6, cc = c & 63;
           const f32x4 v = *(const f32x4*)(smem + row * pitch + cc * 16) + rr[it];
-          *(f32x4*)(cbase + (int64_t)row * p.ldc * 4 + cc * 16) = v;
+          if (ICL_EPI_NT & 1) __builtin_nontemporal_store(v, (f32x4*)(cbase + (int64_t)row * p.ldc * 4 + cc * 16));
+          else *(f32x4*)(cbase + (int64_t)row * p.ldc * 4 + cc * 16) = v;
         }
       } else {
         // all of a thread's row pieces are read from LDS first (independent reads in flight together), then stored: the loop
@@ -415,7 +433,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmParams p_in, R
         for (int it = 0; it < 16; ++it)
           if (it < n_iter) {
             const int c = tid + it * 512, row = c / chunks_per_row, cc = c - row * chunks_per_row;
-            *(u32x4*)(cbase + (int64_t)row * p.ldc * es + cc * 16) = v[it];
+            if ((ICL_EPI_NT & 2) && !slab_out) __builtin_nontemporal_store(v[it], (u32x4*)(cbase + (int64_t)row * p.ldc * es + cc * 16));
+            else *(u32x4*)(cbase + (int64_t)row * p.ldc * es + cc * 16) = v[it];
           }
       }
     }

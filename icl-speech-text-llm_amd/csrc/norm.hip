@@ -10,8 +10,11 @@ namespace {
 constexpr int NT = 256;
 constexpr int MAXN = 8192;  // 64 lanes x 4 x 32 chunks
 
+#ifndef ICL_NORM_NT
+#define ICL_NORM_NT 0     // A/B: non-temporal loads of the f32 input stream (read once per norm)
+#endif
 __device__ __forceinline__ f32x4 load4(const void* base, int64_t off, int dtype) {
-  if (dtype == ICL_F32) return *(const f32x4*)((const float*)base + off);
+  if (dtype == ICL_F32) return ICL_NORM_NT ? __builtin_nontemporal_load((const f32x4*)((const float*)base + off)) : *(const f32x4*)((const float*)base + off);
   const u32x2 raw = *(const u32x2*)((const unsigned short*)base + off);
   return f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
                __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(NT) void norm_kernel(const void* x, int64_t ldx, co
 // loads in flight.  Same two-pass f32 statistics as norm_kernel.
 __device__ __forceinline__ void load8(const void* base, int64_t off, int dtype, float (&v)[8]) {
   if (dtype == ICL_F32) {
-    const f32x4 a = *(const f32x4*)((const float*)base + off), b = *(const f32x4*)((const float*)base + off + 4);
+    const f32x4 a = ICL_NORM_NT ? __builtin_nontemporal_load((const f32x4*)((const float*)base + off)) : *(const f32x4*)((const float*)base + off);
+    const f32x4 b = ICL_NORM_NT ? __builtin_nontemporal_load((const f32x4*)((const float*)base + off + 4)) : *(const f32x4*)((const float*)base + off + 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v[r] = a[r]; v[4 + r] = b[r]; }
   } else {
