@@ -949,7 +949,12 @@ def main():
             cb = {"value": round(1.0 / dt, 5), "unit": "utterances/s", "cores": threads, "kind": "port",
                   "sample": f"1 utterance of the same C2 workload (30 s audio, 376 positions, 10 greedy tokens), fp32 torch-CPU "
                             f"oracle, batch 1, {dt:.1f} s", "utterances": 1, "tokens": cpu_tokens,
-                  "tokens_match_gpu": cpu_tokens == first_tokens}
+                  "tokens_match_gpu": cpu_tokens == first_tokens,
+                  "tokens_note": "informational: under the frozen N(0, 0.02^2) weights the fp32 oracle's top-1 margins are ~0.01 logits "
+                                 "against a bf16-vs-fp32 logit distance of ~0.2 (parity block: the oracle's own two precisions differ by "
+                                 "3.3e-2 relative), so greedy ids of the two precisions may part at a near-tie; what is asserted is "
+                                 "parity.decode_steps_teacher_forced (every GPU choice within 2x the logit error of the oracle's arg-max) "
+                                 "and token-for-token equality on the decisive-margin weights (tokens_match_gpu_on_margin_weights)"}
             rec = os.path.join(ROOT, "profiles", "r02_cpu_baseline_full.json")
             if os.path.exists(rec):     # the full BASELINE.md §3 protocol, recorded once with --cpu-baseline-full on an MI355X host
                 try:

@@ -64,6 +64,9 @@ _SIGNATURES = {
     "icl_attn_fwd_bf16": (c_int, [POINTER(AttnArgs), c_void_p]),
     "icl_attn_decode_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                      c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "icl_attn_decode_rope_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
+                                          c_void_p]),
     "icl_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64,
                               c_void_p, c_int64, c_int32, c_int32, c_float, c_int32, c_int32, c_void_p]),
     "icl_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float,
@@ -312,6 +315,19 @@ def attn_decode(q, kcache, vcache, out, lens, n_heads: int, head_dim: int, max_l
                                                out.data_ptr(), out.stride(0), lens.data_ptr(), q.shape[0],
                                                n_heads, head_dim, max_len, scale, _stream()),
            "icl_attn_decode_bf16")
+    return out
+
+
+def attn_decode_rope(qkv, k_off: int, v_off: int, cos, sin, pos, seq_ids, kcache, vcache, out, lens, n_heads: int,
+                     head_dim: int, max_len: int, scale: float):
+    """One decode step's RoPE + cache append + attention in one launch (icl_attn_decode_rope_bf16): bit-identical to
+    ``rope_kv`` followed by ``attn_decode``; ``qkv`` is left as the projection wrote it."""
+    _require_gpu(qkv, cos, sin, pos, seq_ids, kcache, vcache, out, lens)
+    assert lens.dtype == torch.int32 and pos.dtype == torch.int32 and qkv.dtype == torch.bfloat16
+    _check(load_library().icl_attn_decode_rope_bf16(qkv.data_ptr(), qkv.stride(0), k_off, v_off, cos.data_ptr(), sin.data_ptr(),
+                                                    pos.data_ptr(), _ptr(seq_ids), kcache.data_ptr(), vcache.data_ptr(),
+                                                    out.data_ptr(), out.stride(0), lens.data_ptr(), qkv.shape[0], n_heads,
+                                                    head_dim, max_len, scale, _stream()), "icl_attn_decode_rope_bf16")
     return out
 
 

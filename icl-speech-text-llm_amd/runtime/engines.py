@@ -392,6 +392,7 @@ class SpeechQFormerHIP:
 class LlamaHIP:
     decode_packed_weights = True     # micro-batch <= 256: decode GEMMs stream decode-packed copies of the layer weights
     fuse_decode_norms = True         # decode: o_proj / down_proj + the RMSNorm that follows them in one call (icl_gemm_rmsnorm_bf16)
+    fuse_decode_rope = True          # decode: RoPE + K/V append inside the attention launch (icl_attn_decode_rope_bf16)
 
     # Decode GEMMs at 129..256 rows that run on the 256x256 tile with split-K instead of the decode tile (tile 5).  Measured at the
     # Llama-2-7B shapes, 256 rows, GEMM + slab reduction (tools/decode_gemm_time.py, profiles/r04_decode_gemm_ab.txt): qkv 54.8 us on
@@ -435,7 +436,8 @@ class LlamaHIP:
 
     # ---- one decoder layer over M packed rows ---------------------------------------------------
     def _layer(self, ws: Workspace, L, h, M: int, tag: str, attn_fn, pos, seq_ids, kc, vc, max_len: int,
-               split: Optional[dict] = None, kv_rows_to_c: bool = True, xn_ready: bool = False, next_norm=None):
+               split: Optional[dict] = None, kv_rows_to_c: bool = True, xn_ready: bool = False, next_norm=None,
+               attn_does_rope: bool = False):
         """``xn_ready``: the previous call has already written this layer's normalised input (decode: fused into the reduction
         of the previous down_proj).  ``next_norm`` = (gamma, out bf16 [M, >= hidden]) of the RMSNorm that follows this layer
         (the next layer's input norm into the same ``xn`` buffer, or the final norm): decode fuses it into the down_proj's
@@ -473,7 +475,8 @@ class LlamaHIP:
         else:
             B.gemm(xn, weight_of("qkv", 0, L.wqkv), qkv, bias=L.bqkv, split_k=sk.get("qkv", 1),
                    workspace=wsk, tile=tile_of("qkv"), N=3 * hd, K=w.k_aug)
-            B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
+            if not attn_does_rope:      # decode: RoPE + cache append run inside the attention launch (icl_attn_decode_rope_bf16)
+                B.rope_kv(qkv, hd, 2 * hd, w.rope_cos, w.rope_sin, pos, seq_ids, kc, vc, H, D, max_len, M=M)
         attn_fn(qkv, att)
         fuse = split is not None and self.fuse_decode_norms
         if fuse:     # decode: h += att Wo^T and the post-attention RMSNorm in one call (one kernel when the GEMM is split-K)
@@ -586,12 +589,17 @@ class LlamaHIP:
         for i, L in enumerate(layers):
             kc, vc = cache.k[i], cache.v[i]
 
-            def attn(qkv, att, kc=kc, vc=vc):
-                B.attn_decode(qkv[:, :c.hidden], kc, vc, att, lens, H, D, cache.max_len, D ** -0.5)
+            if self.fuse_decode_rope:      # one launch: rotate q / k at pos, append k / v, attend (bit-identical to the two launches)
+                def attn(qkv, att, kc=kc, vc=vc):
+                    B.attn_decode_rope(qkv, c.hidden, 2 * c.hidden, self.w.rope_cos, self.w.rope_sin, pos, sid, kc, vc, att, lens,
+                                       H, D, cache.max_len, D ** -0.5)
+            else:
+                def attn(qkv, att, kc=kc, vc=vc):
+                    B.attn_decode(qkv[:, :c.hidden], kc, vc, att, lens, H, D, cache.max_len, D ** -0.5)
 
             nxt = (layers[i + 1].rms1, xn_next) if i + 1 < len(layers) else (self.w.norm, xn_final)
             ready = self._layer(ws, L, h, Bn, "dc_", attn, pos, sid, kc, vc, cache.max_len, split=split, xn_ready=ready,
-                                next_norm=nxt)
+                                next_norm=nxt, attn_does_rope=self.fuse_decode_rope)
         return self.logits(ws, h, name="dc_logits", xn_ready=ready)
 
 

@@ -160,6 +160,21 @@ int icl_attn_decode_bf16(const void* Q, int64_t ldq, const void* Kc, const void*
                          int64_t ldo, const int32_t* lens, int32_t n_seqs, int32_t n_heads,
                          int32_t head_dim, int32_t max_len, float scale, void* stream);
 
+/* ---- K11: the decode step's RoPE + KV-cache append + attention as ONE launch --------------------
+ * icl_rope_kv_bf16 (M = n_seqs rows, one new position each) followed by icl_attn_decode_bf16, fused: qkv bf16 [n_seqs][ld] holds
+ * the QKV projection's raw q | k | v row of every sequence (column blocks at 0 | k_off | v_off, n_heads*head_dim wide);
+ * for sequence b the kernel rotates q and k at position pos[b] (cos / sin f32 [max_pos][head_dim/2]), appends the rotated k
+ * and v to cache row seq_ids[b] (NULL: b) at position pos[b], and attends over lens[b] = pos[b] + 1 keys — the appended
+ * one taken from registers.  Same rounding points as the two calls (rope_rot8, bf16 q / k): bit-identical output and cache.
+ * The qkv buffer is NOT modified (icl_rope_kv_bf16 rotates it in place; nothing reads it afterwards).
+ * Replaces apply_rotary_pos_emb + DynamicCache.update + the attention of transformers' LlamaAttention in a decode step
+ * (HF generate loop behind models/custom_salmon.py:704-720).
+ */
+int icl_attn_decode_rope_bf16(const void* qkv, int64_t ld, int64_t k_off, int64_t v_off, const float* cos, const float* sin,
+                              const int32_t* pos, const int32_t* seq_ids, void* kcache, void* vcache, void* O, int64_t ldo,
+                              const int32_t* lens, int32_t n_seqs, int32_t n_heads, int32_t head_dim, int32_t max_len,
+                              float scale, void* stream);
+
 /* ---- K3/K5/K6/K7: LayerNorm;  K10/K14: RMSNorm -----------------------------------------
  * LayerNorm: v = x[m][:] + (res ? alpha * res[m][:] : 0);
  *            y[m][:] = (v - mean(v)) * rsqrt(var(v) + eps) * gamma + beta   (biased variance)

@@ -404,6 +404,43 @@ def test_attn_decode_rounds_the_same_in_any_batch(B, D, H):
         assert torch.equal(few, big[:n])
 
 
+@pytest.mark.parametrize("D,H,Bn", [(128, 32, 1), (128, 4, 7), (64, 6, 5), (128, 32, 40)])
+def test_attn_decode_rope_is_the_two_launches_fused(B, D, H, Bn):
+    """icl_attn_decode_rope_bf16 = icl_rope_kv_bf16 (one new position per sequence) + icl_attn_decode_bf16 in ONE launch: the same
+    attention output and the same appended cache rows, bit for bit (rope_rot8 and the bf16 rounding of q / k are shared); cache rows
+    through a seq_ids indirection; the qkv buffer is left untouched; few and many workgroups."""
+    max_len, hd = 448, H * D
+    g = torch.Generator().manual_seed(77 + Bn)
+    pos = torch.randint(0, max_len - 1, (Bn,), generator=g, dtype=torch.int32)
+    pos[0] = 0 if Bn > 1 else 385
+    if Bn > 2:
+        pos[1], pos[2] = max_len - 1, 63
+    lens = (pos + 1).to(DEV)
+    pos = pos.to(DEV)
+    sid = torch.randperm(Bn, generator=g).to(torch.int32).to(DEV)            # sequence b lives in cache row sid[b]
+    qkv = _rand_bf16(Bn, 3 * hd + 64, seed=78)                              # a row stride wider than 3 * hd
+    kc, vc = _rand_bf16(Bn, H, max_len, D, seed=79), _rand_bf16(Bn, H, max_len, D, seed=80)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2, device=DEV).float() / D))
+    ang = torch.arange(max_len, device=DEV).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    # reference: the two launches (rope_kv rotates qkv in place and appends; attention reads cache rows in sequence order)
+    qkv_a, kc_a, vc_a = qkv.clone(), kc.clone(), vc.clone()
+    B.rope_kv(qkv_a, hd, 2 * hd, cos, sin, pos, sid, kc_a, vc_a, H, D, max_len)
+    want = torch.empty(Bn, hd, dtype=torch.bfloat16, device=DEV)
+    order = sid.long()
+    B.attn_decode(qkv_a[:, :hd], kc_a[order].contiguous(), vc_a[order].contiguous(), want, lens, H, D, max_len, D ** -0.5)
+    # fused
+    qkv_b, kc_b, vc_b = qkv.clone(), kc.clone(), vc.clone()
+    got = torch.empty(Bn, hd, dtype=torch.bfloat16, device=DEV)
+    B.attn_decode_rope(qkv_b, hd, 2 * hd, cos, sin, pos, sid, kc_b, vc_b, got, lens, H, D, max_len, D ** -0.5)
+    assert torch.equal(got, want)
+    assert torch.equal(kc_b, kc_a) and torch.equal(vc_b, vc_a) and torch.equal(qkv_b, qkv)
+    for b in range(Bn):                                                      # and the appended rows are where they belong
+        assert not torch.equal(kc_b[int(sid[b]), :, int(pos[b])], kc[int(sid[b]), :, int(pos[b])])
+    with pytest.raises(B.IclError):
+        B.attn_decode_rope(qkv_b, hd, hd, cos, sin, pos, sid, kc_b, vc_b, got, lens, H, D, max_len, D ** -0.5)    # k and v blocks overlap
+
+
 # ------------------------------------------------------------------------------------------------
 # norms / element-wise
 # ------------------------------------------------------------------------------------------------
