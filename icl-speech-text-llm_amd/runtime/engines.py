@@ -392,7 +392,7 @@ class SpeechQFormerHIP:
 class LlamaHIP:
     decode_packed_weights = True     # micro-batch <= 256: decode GEMMs stream decode-packed copies of the layer weights
     fuse_decode_norms = True         # decode: o_proj / down_proj + the RMSNorm that follows them in one call (icl_gemm_rmsnorm_bf16)
-    fuse_decode_rope = True          # decode: RoPE + K/V append inside the attention launch (icl_attn_decode_rope_bf16)
+    fuse_decode_rope = os.environ.get("ICL_FUSE_DECODE_ROPE", "1") != "0"   # decode: RoPE + K/V append inside the attention launch (icl_attn_decode_rope_bf16)
 
     # Decode GEMMs at 129..256 rows that run on the 256x256 tile with split-K instead of the decode tile (tile 5).  Measured at the
     # Llama-2-7B shapes, 256 rows, GEMM + slab reduction (tools/decode_gemm_time.py, profiles/r04_decode_gemm_ab.txt): qkv 54.8 us on
@@ -589,7 +589,12 @@ class LlamaHIP:
         for i, L in enumerate(layers):
             kc, vc = cache.k[i], cache.v[i]
 
-            if self.fuse_decode_rope:      # one launch: rotate q / k at pos, append k / v, attend (bit-identical to the two launches)
+            # One launch: rotate q / k at pos, append k / v, attend — bit-identical to the two launches, so the choice is free.
+            # Same-box A/B (tools/ab_decode_rope.sh, profiles/r04_decode_rope_ab.txt): at 256 rows decode 143.2 -> 142.5 ms; at ONE
+            # sequence 58.4 -> 59.6 ms per utterance — the rotation's dependent loads (pos -> cos / sin, q, k) sit in front of a
+            # latency-bound attention and cost more than the 5-us launch they replace — so small batches keep the two launches.
+            fuse_rope = self.fuse_decode_rope and Bn > 8
+            if fuse_rope:
                 def attn(qkv, att, kc=kc, vc=vc):
                     B.attn_decode_rope(qkv, c.hidden, 2 * c.hidden, self.w.rope_cos, self.w.rope_sin, pos, sid, kc, vc, att, lens,
                                        H, D, cache.max_len, D ** -0.5)
@@ -599,7 +604,7 @@ class LlamaHIP:
 
             nxt = (layers[i + 1].rms1, xn_next) if i + 1 < len(layers) else (self.w.norm, xn_final)
             ready = self._layer(ws, L, h, Bn, "dc_", attn, pos, sid, kc, vc, cache.max_len, split=split, xn_ready=ready,
-                                next_norm=nxt, attn_does_rope=self.fuse_decode_rope)
+                                next_norm=nxt, attn_does_rope=fuse_rope)
         return self.logits(ws, h, name="dc_logits", xn_ready=ready)
 
 
