@@ -228,7 +228,10 @@ void launch_norm(hipStream_t st, const void* x, int64_t ldx, const void* res, fl
   // N <= 1024 (BEATs), N = 4096 and the residual / dual-output forms are as fast or faster on the one-row-per-wave kernel.
   // The choice depends on N and the call form only, never on M: a row must round the same in any batch.
   const int pl8 = ((N >> 3) + 63) / 64;
-  if (N % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && !res && !y2 && a32 && N <= 5120 && (pl8 == 3 || pl8 > 8)) {
+#ifndef ICL_NORM8_ALL
+#define ICL_NORM8_ALL 0      // A/B: route every eligible shape to the streaming variant
+#endif
+  if (N % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && !res && !y2 && a32 && N <= 5120 && (ICL_NORM8_ALL || pl8 == 3 || pl8 > 8)) {
     static int n_cu = 0;
     if (n_cu <= 0) {
       n_cu = icl_device_cu_count();
