@@ -295,12 +295,11 @@ class ArenaBatchLoader:
                     recycle(block=True)
                     continue
                 try:
-                    r = self._result_q.get(True, self.timeout) if block else self._result_q.get_nowait()
+                    r = self._get_result() if block else self._result_q.get_nowait()
                 except queue.Empty:
                     if not block:
                         return None
-                    dead = [p.pid for p in self._workers if not p.is_alive()]
-                    raise RuntimeError(f"batch loader: no batch within {self.timeout:.0f} s" + (f" (workers {dead} died)" if dead else ""))
+                    raise
                 outstanding -= 1
                 done[r[0]] = r
             b_no, slot, kind, payload, err = done.pop(b)
@@ -334,7 +333,7 @@ class ArenaBatchLoader:
             # an early exit leaves tasks in the workers: let them finish before the slots are used again
             while outstanding > 0 and self.num_workers > 0:
                 try:
-                    self._result_q.get(True, self.timeout)
+                    self._get_result()
                 except Exception:
                     break
                 outstanding -= 1
@@ -342,6 +341,22 @@ class ArenaBatchLoader:
                 recycle(block=True)
                 while copying:
                     recycle(block=True)
+
+    def _get_result(self):
+        """Next finished batch from the workers; a worker that has died (killed, out of memory) is noticed within seconds instead of
+        after the whole timeout — its batch would never arrive."""
+        waited = 0.0
+        while True:
+            try:
+                return self._result_q.get(True, 5.0)
+            except queue.Empty:
+                waited += 5.0
+                dead = [p.pid for p in self._workers if not p.is_alive()]
+                if dead:
+                    raise RuntimeError(f"batch loader: worker process(es) {dead} died (exit codes "
+                                       f"{[p.exitcode for p in self._workers if not p.is_alive()]}); no batch will arrive from them")
+                if waited >= self.timeout:
+                    raise RuntimeError(f"batch loader: no batch within {self.timeout:.0f} s")
 
     def _inline(self, b: int, slot: int):
         arena = self._arenas[slot]

@@ -208,3 +208,34 @@ def test_cli_defaults_follow_the_host_and_the_model(monkeypatch):
     assert 1 <= cli.usable_cores.__wrapped__() if hasattr(cli.usable_cores, "__wrapped__") else True
     model = SimpleNamespace(cfg=SimpleNamespace(llama=SimpleNamespace(hidden=4096, n_layers=32)))
     assert cli.auto_batch_size(model, "cpu") == 8 and cli.auto_batch_size(SimpleNamespace(), "cpu") == 8
+
+
+def test_arena_batch_loader_notices_a_dead_worker():
+    """A worker that is killed (the OOM killer, a segfault in a decoder) must not leave the main process waiting for its batch for
+    the whole timeout: the loader sees the dead process within seconds and raises."""
+    import os
+    import signal
+    from icl_speech_text_llm_amd.utils.batch_loader import ArenaBatchLoader
+
+    class Suicide(torch.utils.data.Dataset):
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            if i == 2:
+                os.kill(os.getpid(), signal.SIGKILL)
+            return {"raw_wav": torch.full((10,), float(i))}
+
+    def collate(items):
+        from icl_speech_text_llm_amd.data.model_processors import _pad_rows
+        return {"raw_wav": _pad_rows([it["raw_wav"] for it in items])}
+
+    ld = ArenaBatchLoader(Suicide(), 2, collate, num_workers=1, device="cpu", timeout=120)
+    try:
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="died"):      # (batch 0 may be lost with the worker: its queue feeder dies too)
+            for _ in ld:
+                pass
+        assert time.perf_counter() - t0 < 30
+    finally:
+        ld.close()
