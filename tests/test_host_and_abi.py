@@ -144,8 +144,8 @@ def fake_generate_ids(self, samples, want_first_logits=False):
     return GenerateResult(tokens=toks, first_logits=first, dropped=drop)
 cs.CustomSALMONN.generate_ids = fake_generate_ids
 args = parse_args(["--peft_model_path", "", "--run_name", "dp", "--dataset_type", "voxceleb-hvb", "--device", "cpu",
-                   "--arch", "tiny", "--synthetic_items", "5", "--batch_size", "2", "--num_workers", "0",
-                   "--input_mode", "text_only", "--results_dir", sys.argv[2]])
+                   "--arch", "tiny", "--synthetic_items", "5", "--batch_size", "2", "--num_workers", os.environ.get("DP_WORKERS", "0"),
+                   "--input_mode", os.environ.get("DP_INPUT_MODE", "text_only"), "--results_dir", sys.argv[2]])
 out = run_inference(args)
 if int(os.environ["RANK"]) == 0:
     json.dump({"n": len(out["results"]), "texts": [r["text"] for r in out["results"]],
@@ -204,6 +204,13 @@ def test_data_parallel_sharding_gloo_world2(tmp_path):
     s2 = _run_dp(script, tmp_path / "s2", 2, 29619, {"DP_STANDIN": "1"})
     assert s1["n"] == s2["n"] == 10 and s1["preds"] == s2["preds"] and s1["preds"][0].startswith("neutral")
     assert s1["label_logits"] == s2["label_logits"] and s1["label_logits"][0]
+    # round 4: every rank feeds itself through ArenaBatchLoader WORKER PROCESSES (collate into shared slots; speech_only items carry
+    # waveforms through the arenas) — same records as the in-process loader
+    (tmp_path / "k0").mkdir()
+    (tmp_path / "k2").mkdir()
+    k0 = _run_dp(script, tmp_path / "k0", 2, 29621, {"DP_INPUT_MODE": "speech_only"})
+    k2 = _run_dp(script, tmp_path / "k2", 2, 29623, {"DP_INPUT_MODE": "speech_only", "DP_WORKERS": "2"})
+    assert k0["n"] == k2["n"] == 10 and k0["texts"] == k2["texts"] and k0["preds"] == k2["preds"] and k2["missing"] == []
 
 
 _BENCH_DP_SCRIPT = r"""
