@@ -545,6 +545,7 @@ def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batche
         barrier()
         t_end = time.perf_counter()
         overflow = loader.overflow_batches
+        pinned = f"{loader.slots_pinned}/{depth}"
     finally:
         loader.close()
     dt = t_end - t_start
@@ -574,7 +575,7 @@ def through_plugin(args, dev, dist=None, rank: int = 0, world: int = 1, n_batche
                 "host_stage_ms_last_batch": stages[-1] if stages else None,
                 "generate_output_ms": {"min": min(gen_ms), "median": _median(gen_ms), "max": max(gen_ms)},
                 "between_batches_ms": {"min": min(gaps), "median": _median(gaps), "max": max(gaps)} if gaps else None,
-                "slot_overflow_batches": overflow,
+                "slot_overflow_batches": overflow, "slots_page_locked": pinned,
                 "utt_per_s_steady": round(steady, 2) if steady else None,
                 "prompt_positions_first_rows": [t + N_AUDIO_TOK for t in prompt_tokens], "note": note}
     # ---- world > 1: MAX over ranks, every rank's figures to rank 0 (objects, outside the timed region) ----------------------

@@ -190,6 +190,11 @@ class ArenaBatchLoader:
     def __len__(self) -> int:
         return len(self._order)
 
+    @property
+    def slots_pinned(self) -> int:
+        """How many of the collate slots are page-locked (all of them on a GPU device unless registration failed)."""
+        return sum(1 for a in self._arenas if a.pinned)
+
     # ---- set-up / tear-down ---------------------------------------------------------------------------------------
     def _start(self) -> None:
         if self._arenas or not self._order:
