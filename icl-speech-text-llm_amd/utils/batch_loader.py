@@ -293,10 +293,10 @@ class ArenaBatchLoader:
                 if b in done:
                     break
                 if outstanding == 0:             # not dispatched: every slot sits behind an H2D copy (or holds a finished batch)
-                    if not copying:
-                        raise RuntimeError("batch loader: no free slot and nothing in flight (slots < 2?)")
                     if not block:
                         return None
+                    if not copying:
+                        raise RuntimeError("batch loader: no free slot and nothing in flight")
                     recycle(block=True)
                     continue
                 try:
@@ -380,10 +380,14 @@ class ArenaBatchLoader:
         if self.device.type != "cuda":
             return batch, None, slot
         import copy
+        arena = self._arenas[slot]
         with torch.cuda.stream(self._side):
             out = copy.copy(batch)
             out.update({k: v.to(self.device, non_blocking=True) for k, v in batch.items()
                         if isinstance(v, torch.Tensor) and v.is_floating_point()})
+        for k, v in batch.items():      # anything else a collate placed in the slot must not outlive the slot's recycling
+            if isinstance(v, torch.Tensor) and not v.is_floating_point() and arena.offset_of(v) is not None:
+                out[k] = v.clone()
         ev = torch.cuda.Event()
         ev.record(self._side)
         copying.append((ev, slot))
