@@ -535,7 +535,10 @@ int iclg::launch_tile256(GemmParams& p, int batch, hipStream_t stream, const Rop
     // the best gm keeps an XCD's A side near 8 MB — 1-2 at K = 11008, 3-4 at K = 4096-5120, 4-6 at K <= 1280; gm = 8 (rounds
     // 1-2) cost 1.5-3.5 % at K >= 4096 and gm = 16 / 32 cost 8 / 16 %.
     static const int env_gm = [] { const char* e = getenv("ICL_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();   // tuning knobs
-    static const int env_xs = [] { const char* e = getenv("ICL_GEMM_XCD_SYNC"); return e ? atoi(e) : 0; }();   // (tools/gemm_ab.py)
+    // XCD-synchronised super-tile map (block_to_tile): on since round 4 — with the outputs no longer cached (non-temporal stores) the
+    // eight XCDs sweeping the same N range together is worth 6-9 ms of a 1790 ms step in five interleaved same-box rounds
+    // (profiles/r04_gemm_xcd_sync_ab.txt; within +-0.7 % in round 3's isolated-GEMM test).  ICL_GEMM_XCD_SYNC=0 restores the contiguous split.
+    static const int env_xs = [] { const char* e = getenv("ICL_GEMM_XCD_SYNC"); return e ? atoi(e) : 1; }();
     const int64_t panel = (int64_t)256 * p.K * 2;
     p.group_m = env_gm > 0 ? env_gm : (int)std::min<int64_t>(6, std::max<int64_t>(1, 8400000 / panel));
     p.xcd_sync = env_xs;
