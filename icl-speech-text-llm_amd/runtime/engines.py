@@ -396,9 +396,10 @@ class LlamaHIP:
 
     # Decode GEMMs at 129..256 rows that run on the 256x256 tile with split-K instead of the decode tile (tile 5).  Measured at the
     # Llama-2-7B shapes, 256 rows, GEMM + slab reduction (tools/decode_gemm_time.py, profiles/r04_decode_gemm_ab.txt): qkv 54.8 us on
-    # the decode tile -> 46.6 (split 4); o 32.2 -> 29.5 (split 8); gate/up 79.6 -> 67.1 (split 2); down 48.5 -> 49.7: stays.
-    # ICL_DECODE_T256 = comma list of qkv / o / gu / down overrides the set ("" = decode tile only).
-    decode_t256 = tuple(x for x in os.environ.get("ICL_DECODE_T256", "qkv,o,gu").split(",") if x)
+    # the decode tile -> 46.6 (split 4); o 32.2 -> 29.5 (split 8); gate/up 79.6 -> 67.1 (split 2); down 48.5 -> 49.7 stand-alone, but
+    # IN SITU (tools/ab_env.sh, four interleaved rounds: profiles/r04_decode_gemm_ab.txt) the decode phase is 2.3 ms faster with `down`
+    # on the 256 tile as well (split 12) — all four.  ICL_DECODE_T256 = comma list of qkv / o / gu / down overrides ("" = decode tile only).
+    decode_t256 = tuple(x for x in os.environ.get("ICL_DECODE_T256", "qkv,o,gu,down").split(",") if x)
 
     def _t256_split(self, N: int, K: int) -> int:
         """Split-K of a 256-row decode GEMM on the 256x256 tile: one M-tile, ceil(N / 256) N-tiles; the slices fill ~80 % of the
