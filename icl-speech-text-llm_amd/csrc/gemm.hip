@@ -235,6 +235,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   }
 }
 
+// sum of `split` slabs at `src` (stride `slab` floats) in slab order, four loads in flight at a time: the adds keep their order
+// (bit-identical to the one-load-at-a-time loop), the loads no longer wait for each other (a row-per-block reduction runs one
+// wave per SIMD: nothing else hides a ~2 us round trip per slab)
+__device__ __forceinline__ f32x4 sum_slabs4(const float* src, int64_t slab, int split) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= split; s += 4) {
+    const f32x4 a = *(const f32x4*)(src + (s + 0) * slab), b = *(const f32x4*)(src + (s + 1) * slab);
+    const f32x4 c = *(const f32x4*)(src + (s + 2) * slab), d = *(const f32x4*)(src + (s + 3) * slab);
+    v = v + a;
+    v = v + b;
+    v = v + c;
+    v = v + d;
+  }
+  for (; s < split; ++s) v = v + *(const f32x4*)(src + s * slab);
+  return v;
+}
+
 // split-K reduction + epilogue.  Vector form (every layout 4-element aligned — the decode GEMMs): one thread per FOUR consecutive
 // output columns, 16-B loads of the slabs / residual and one 8- or 16-B store; each element still sums its slabs in slab order,
 // then bias, activation, residual — the scalar form's arithmetic, bit for bit (round 4: 10.9 us per call at 256 x 12288 x 4 slabs
@@ -255,11 +273,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
       f32x4 v;
       if (swiglu) {
         const int ng = (c >> 4) * 32 + (c & 15), nu = ng + 16;      // 4 consecutive outputs stay inside one 16-column gate block
-        f32x4 g = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.split_k; ++s) {
-          g = g + *(const f32x4*)(p.ws + s * slab + (int64_t)m * p.N + ng);
-          u = u + *(const f32x4*)(p.ws + s * slab + (int64_t)m * p.N + nu);
-        }
+        f32x4 g = sum_slabs4(p.ws + (int64_t)m * p.N + ng, slab, p.split_k);
+        f32x4 u = sum_slabs4(p.ws + (int64_t)m * p.N + nu, slab, p.split_k);
         if (p.epi & ICL_EPI_BIAS) {
           g = g + *(const f32x4*)(p.bias + ng);
           u = u + *(const f32x4*)(p.bias + nu);
@@ -267,8 +282,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(g[r]) * u[r];
       } else {
-        v = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.split_k; ++s) v = v + *(const f32x4*)(p.ws + s * slab + (int64_t)m * p.N + c);
+        v = sum_slabs4(p.ws + (int64_t)m * p.N + c, slab, p.split_k);
         if (p.epi & ICL_EPI_BIAS) v = v + *(const f32x4*)(p.bias + c);
         if (p.epi & ICL_EPI_GELU) v = gelu_erf4(v);
         if (p.epi & ICL_EPI_RESIDUAL) v = v + *(const f32x4*)((const float*)p.R + (int64_t)m * p.ldr + c);
@@ -333,10 +347,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(GemmParams p
   for (int i = 0; i < VPT; ++i) {
     const int c = tid + i * 256;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c < nvec) {
-      const float* src = p.ws + (int64_t)m * p.N + c * 4;
-      for (int s_ = 0; s_ < p.split_k; ++s_) v[i] = v[i] + *(const f32x4*)(src + s_ * slab);
-    }
+    if (c < nvec) v[i] = sum_slabs4(p.ws + (int64_t)m * p.N + c * 4, slab, p.split_k);
   }
   float ss = 0.f;
 #pragma unroll
