@@ -888,6 +888,19 @@ extern "C" int icl_gemm_rmsnorm_bf16(const icl_gemm_args* a, const float* gamma,
   // is an L2 write-back; tools/skinny_tail_time.py)
   const int rc = gemm_impl(a, stream, nullptr);            // no slabs to reduce: the GEMM's own epilogue, then the plain norm
   if (rc != ICL_OK) return rc;
+#ifndef ICL_SMALL_M_BLOCKNORM
+#define ICL_SMALL_M_BLOCKNORM 1   // round 4: 58.7 -> 56.7 ms per utterance at one sequence (tools/ab_bench_b1.sh, profiles/r04_skinny_tail_ab.txt)
+#endif
+  if (ICL_SMALL_M_BLOCKNORM && a->M <= 64 && a->ldc == a->N) {
+    // few rows (a decode step of <= 64 sequences): the row-per-block kernel of the split-K path (four waves per row) over the
+    // finished rows as a single "slab" — the one-wave-per-row norm_kernel is a 9-us latency chain at one row
+    GemmParams q{};
+    q.ws = (float*)a->C; q.C = a->C; q.R = nullptr; q.ldc = a->ldc; q.ldr = 0; q.M = a->M; q.N = a->N; q.split_k = 1; q.epi = 0;
+    if (a->N <= 4096) hipLaunchKernelGGL(splitk_reduce_rmsnorm_kernel<4>, dim3(a->M), dim3(256), 0, (hipStream_t)stream, q, gamma, eps, (unsigned short*)xn, ld_xn);
+    else              hipLaunchKernelGGL(splitk_reduce_rmsnorm_kernel<8>, dim3(a->M), dim3(256), 0, (hipStream_t)stream, q, gamma, eps, (unsigned short*)xn, ld_xn);
+    ICL_CHECK_LAUNCH("icl_gemm_rmsnorm_bf16(row-per-block RMSNorm)");
+    return ICL_OK;
+  }
   return icl_rmsnorm(a->C, a->ldc, gamma, xn, ld_xn, a->M, a->N, eps, ICL_F32, ICL_BF16, stream);
 }
 
