@@ -10,7 +10,7 @@ if os.environ.get("ICL_LIB"):
     B.LIB_PATH = os.environ["ICL_LIB"]      # A/B against another build of the library (same box, same call)
 B.load_library()
 which = sys.argv[1] if len(sys.argv) > 1 else "whisper"
-nseq, L, H, D, causal = {"whisper": (64, 1500, 20, 64, False), "llama": (64, 376, 32, 128, True), "beats": (64, 1496, 12, 64, False),
+nseq, L, H, D, causal = {"whisper": (64, 1500, 20, 64, False), "llama": (64, 376, 32, 128, True), "qwen": (32, 1264, 32, 128, True), "llama600": (64, 600, 40, 128, True), "beats": (64, 1496, 12, 64, False),
                          "beats_bias": (64, 1496, 12, 64, False)}[which]
 nseq = int(os.environ.get("ICL_ATTN_NSEQ", nseq))
 total = nseq * L
